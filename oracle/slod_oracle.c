@@ -1,0 +1,1102 @@
+/*
+ * oracle/slod_oracle.c -- TEST INFRASTRUCTURE ONLY (see slod_oracle.h).
+ *
+ * Plain-C fp64 restatement of the reference algorithm.  Every function cites the
+ * reference lines it follows (paths relative to /root/reference).  Differences from the
+ * reference that do not change the mathematics (documented in DESIGN.md):
+ *   - Amesos-KLU (LODtools.h:378-507) is replaced by a banded Cholesky on A_II
+ *     (X_B = 0 exactly as in the reference because the RHS rows of constrained dofs are
+ *     zeroed, LOD.cc:512-518, and their matrix rows are identity rows, LOD.cc:537-543);
+ *   - LAPACK dgesdd on G = BD'^T BD' (LOD.cc:660-667) is replaced by a one-sided Jacobi
+ *     SVD of BD' (sigma(G) = sigma(BD')^2, same singular vectors); mode 1 reproduces the
+ *     literal Gram-matrix formulation with a Jacobi eigen-solver for cross-checks;
+ *   - dense S_boundary / PT / PT_boundary (LOD.cc:462-467) are applied as stencils.
+ */
+#include "slod_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static int g_svd_mode = 0; /* 0: one-sided Jacobi on BD'; 1: Jacobi eigen on the Gram matrix */
+void so_set_svd_mode(int mode) { g_svd_mode = mode; }
+
+/* ------------------------------------------------------------------------- */
+/* index calculus                                                            */
+/* ------------------------------------------------------------------------- */
+int so_num_cells_per_side(const so_cfg *cfg)
+{
+  return cfg->n_cells > 0 ? cfg->n_cells : (1 << cfg->nref);
+}
+
+int so_num_patches(const so_cfg *cfg)
+{
+  const int N = so_num_cells_per_side(cfg);
+  return N * N;
+}
+
+/* hyper_cube + refine_global: active cells in z-order, child order (0,0),(1,0),(0,1),(1,1)
+ * => x in the even bits (pinned by tests/create_patch_01.output).  The
+ * reference stores patches in active-cell order (LOD.cc:184-192). */
+void so_patch_centre(const so_cfg *cfg, int pid, int *cx, int *cy)
+{
+  if (cfg->n_cells > 0)
+    {
+      *cx = pid % cfg->n_cells;
+      *cy = pid / cfg->n_cells;
+      return;
+    }
+  int x = 0, y = 0;
+  for (int b = 0; b < cfg->nref; ++b)
+    {
+      x |= ((pid >> (2 * b)) & 1) << b;
+      y |= ((pid >> (2 * b + 1)) & 1) << b;
+    }
+  *cx = x;
+  *cy = y;
+}
+
+int so_patch_id_of_cell(const so_cfg *cfg, int cx, int cy)
+{
+  if (cfg->n_cells > 0)
+    return cx + cfg->n_cells * cy;
+  int pid = 0;
+  for (int b = 0; b < cfg->nref; ++b)
+    {
+      pid |= ((cx >> b) & 1) << (2 * b);
+      pid |= ((cy >> b) & 1) << (2 * b + 1);
+    }
+  return pid;
+}
+
+static int imin(int a, int b) { return a < b ? a : b; }
+static int imax(int a, int b) { return a > b ? a : b; }
+
+/* LOD.cc:140-181 (extent), LOD.cc:830-843 (boundary ids), LODtools.h:334-375 (dof sets) */
+void so_patch_init(const so_cfg *cfg, int pid, so_patch *p)
+{
+  const int N = so_num_cells_per_side(cfg);
+  const int l = cfg->oversampling, n = cfg->n_sub, s = cfg->spacedim;
+  p->pid = pid;
+  so_patch_centre(cfg, pid, &p->cx, &p->cy);
+  p->x0 = imax(p->cx - l, 0);
+  p->y0 = imax(p->cy - l, 0);
+  const int x1 = imin(p->cx + l, N - 1), y1 = imin(p->cy + l, N - 1);
+  p->mx = x1 - p->x0 + 1;
+  p->my = y1 - p->y0 + 1;
+  p->nx = n * p->mx;
+  p->ny = n * p->my;
+  p->side_domain[0] = (p->x0 == 0);
+  p->side_domain[1] = (x1 == N - 1);
+  p->side_domain[2] = (p->y0 == 0);
+  p->side_domain[3] = (y1 == N - 1);
+  p->n_f = s * (p->nx + 1) * (p->ny + 1);
+  p->n_i = s * (p->nx - 1) * (p->ny - 1);
+  p->n_c = s * p->mx * p->my;
+  int nb = 0;
+  for (int iy = 0; iy <= p->ny; ++iy)
+    for (int ix = 0; ix <= p->nx; ++ix)
+      {
+        const int on99 = (ix == 0 && !p->side_domain[0]) || (ix == p->nx && !p->side_domain[1]) ||
+                         (iy == 0 && !p->side_domain[2]) || (iy == p->ny && !p->side_domain[3]);
+        nb += on99;
+      }
+  p->n_b    = s * nb;
+  p->is_lod = (!cfg->stabilize) || (l == 0) || (p->mx * p->my == N * N);
+}
+
+int so_patch_cells(const so_cfg *cfg, const so_patch *p, int *cells)
+{
+  const int N = so_num_cells_per_side(cfg);
+  const int l = cfg->oversampling;
+  int       c = 0;
+  cells[c++]  = p->cx + N * p->cy; /* LOD.cc:151-154 */
+  for (int lr = -l; lr <= l; ++lr)
+    {
+      const int x = p->cx + lr;
+      if (x < 0 || x >= N)
+        continue;
+      for (int lc = -l; lc <= l; ++lc)
+        {
+          const int y = p->cy + lc;
+          if (y < 0 || y >= N)
+            continue;
+          if (lr == 0 && lc == 0)
+            continue;
+          cells[c++] = x + N * y;
+        }
+    }
+  return c;
+}
+
+/* ------------------------------------------------------------------------- */
+/* element kernels                                                           */
+/* ------------------------------------------------------------------------- */
+/* gradients of the four bilinear hats on the reference square at (xi,eta); local node
+ * a = ax + 2*ay.  QGauss<1>(2) points (1 -+ 1/sqrt(3))/2 (LOD.cc:91-92). */
+static void hat_gradients(double xi, double eta, double gx[4], double gy[4])
+{
+  gx[0] = -(1.0 - eta);
+  gx[1] = (1.0 - eta);
+  gx[2] = -eta;
+  gx[3] = eta;
+  gy[0] = -(1.0 - xi);
+  gy[1] = -xi;
+  gy[2] = (1.0 - xi);
+  gy[3] = xi;
+}
+
+static void gauss_point(int q, double *xi, double *eta)
+{
+  const double g0 = 0.5 * (1.0 - 1.0 / sqrt(3.0));
+  const double g1 = 0.5 * (1.0 + 1.0 / sqrt(3.0));
+  *xi             = (q & 1) ? g1 : g0;
+  *eta            = (q & 2) ? g1 : g0;
+}
+
+/* Diffusion.h:181-186: alpha_q * grad_i.grad_j * JxW, with JxW = h^2/4 and grad = ghat/h. */
+void so_local_matrix_poisson(const double alpha[4], double K[16])
+{
+  for (int i = 0; i < 16; ++i)
+    K[i] = 0.0;
+  for (int q = 0; q < 4; ++q)
+    {
+      double xi, eta, gx[4], gy[4];
+      gauss_point(q, &xi, &eta);
+      hat_gradients(xi, eta, gx, gy);
+      for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b)
+          K[4 * a + b] += alpha[q] * ((gx[a] * gx[b] + gy[a] * gy[b]) * 0.25);
+    }
+}
+
+/* Elasticity.h:246-258: (2 mu eps_i:eps_j + lambda div_i div_j) JxW. */
+void so_local_matrix_elasticity(const double lambda[4], const double mu[4], double K[64])
+{
+  for (int i = 0; i < 64; ++i)
+    K[i] = 0.0;
+  for (int q = 0; q < 4; ++q)
+    {
+      double xi, eta, g[2][4];
+      gauss_point(q, &xi, &eta);
+      hat_gradients(xi, eta, g[0], g[1]);
+      for (int i = 0; i < 4; ++i)
+        for (int a = 0; a < 2; ++a)
+          for (int j = 0; j < 4; ++j)
+            for (int b = 0; b < 2; ++b)
+              {
+                const double gg  = g[0][i] * g[0][j] + g[1][i] * g[1][j];
+                const double sym = ((a == b) ? gg : 0.0) + g[b][i] * g[a][j];
+                const double dv  = g[a][i] * g[b][j];
+                K[8 * (2 * i + a) + (2 * j + b)] += (mu[q] * sym + lambda[q] * dv) * 0.25;
+              }
+    }
+}
+
+/* FETools::lexicographic_to_hierarchic_numbering: vertices, then lines
+ * (x=0, x=n, y=0, y=n; increasing coordinate), then interior lexicographic. */
+void so_lexicographic_to_hierarchic(int dim, int n, int *map)
+{
+  if (dim == 1)
+    {
+      map[0] = 0;
+      map[n] = 1;
+      for (int i = 1; i < n; ++i)
+        map[i] = 1 + i;
+      return;
+    }
+  const int np = n + 1;
+  int       next;
+  map[0]              = 0;
+  map[n]              = 1;
+  map[n * np]         = 2;
+  map[n * np + n]     = 3;
+  next                = 4;
+  for (int j = 1; j < n; ++j)
+    map[j * np] = next++;
+  for (int j = 1; j < n; ++j)
+    map[j * np + n] = next++;
+  for (int i = 1; i < n; ++i)
+    map[i] = next++;
+  for (int i = 1; i < n; ++i)
+    map[n * np + i] = next++;
+  for (int j = 1; j < n; ++j)
+    for (int i = 1; i < n; ++i)
+      map[j * np + i] = next++;
+}
+
+/* tests/fe_q_iso_q1_01.cc: Laplace cell matrix of FE_Q_iso_Q1(n) on the unit cell. */
+void so_fe_q_iso_q1_cell_matrix(int dim, int n, double *M)
+{
+  const int np  = n + 1;
+  const int nd  = (dim == 1) ? np : np * np;
+  int      *map = (int *)malloc(sizeof(int) * (size_t)nd);
+  so_lexicographic_to_hierarchic(dim, n, map);
+  for (int i = 0; i < nd * nd; ++i)
+    M[i] = 0.0;
+  if (dim == 1)
+    {
+      /* sub-element of length 1/n: [1 -1; -1 1] * n */
+      for (int c = 0; c < n; ++c)
+        for (int a = 0; a < 2; ++a)
+          for (int b = 0; b < 2; ++b)
+            M[map[c + a] * nd + map[c + b]] += (a == b ? 1.0 : -1.0) * (double)n;
+    }
+  else
+    {
+      const double one[4] = {1.0, 1.0, 1.0, 1.0};
+      double       K[16];
+      so_local_matrix_poisson(one, K);
+      for (int c1 = 0; c1 < n; ++c1)
+        for (int c0 = 0; c0 < n; ++c0)
+          for (int a = 0; a < 4; ++a)
+            for (int b = 0; b < 4; ++b)
+              {
+                const int ia = map[(c0 + (a & 1)) + (c1 + (a >> 1)) * np];
+                const int ib = map[(c0 + (b & 1)) + (c1 + (b >> 1)) * np];
+                M[ia * nd + ib] += K[4 * a + b];
+              }
+    }
+  free(map);
+}
+
+/* ------------------------------------------------------------------------- */
+/* assembly                                                                  */
+/* ------------------------------------------------------------------------- */
+static int first_full_patch(const so_cfg *cfg)
+{
+  const int np = so_num_patches(cfg), full = 2 * cfg->oversampling + 1;
+  for (int pid = 0; pid < np; ++pid)
+    {
+      so_patch q;
+      so_patch_init(cfg, pid, &q);
+      if (q.mx == full && q.my == full)
+        return pid;
+    }
+  return -1;
+}
+
+#define ST(node, dir, a, b) stencil[(((size_t)(node)*9 + (dir)) * s + (a)) * s + (b)]
+
+/* assemble_stiffness with empty constraints (LOD.cc:440-444 -> Diffusion.h:143-204 /
+ * Elasticity.h:197-296).  Quirk Q1 (LOD.cc:354-362,446-450): every full patch after the
+ * first one re-uses the first full patch's matrix. */
+void so_assemble_patch(const so_cfg *cfg, const so_patch *p, const double *const *coef,
+                       double *stencil)
+{
+  const int N = so_num_cells_per_side(cfg), n = cfg->n_sub, s = cfg->spacedim;
+  const int NE = N * n;
+  int       ox = p->x0 * n, oy = p->y0 * n;
+  if (cfg->reuse_full && p->mx == 2 * cfg->oversampling + 1 && p->my == 2 * cfg->oversampling + 1)
+    {
+      so_patch f;
+      so_patch_init(cfg, first_full_patch(cfg), &f);
+      ox = f.x0 * n;
+      oy = f.y0 * n;
+    }
+  const int npx = p->nx + 1;
+  memset(stencil, 0, sizeof(double) * (size_t)(npx * (p->ny + 1)) * 9 * s * s);
+  for (int ey = 0; ey < p->ny; ++ey)
+    for (int ex = 0; ex < p->nx; ++ex)
+      {
+        const size_t ge = ((size_t)(oy + ey) * NE + (ox + ex)) * 4;
+        double       K[64];
+        if (s == 1)
+          so_local_matrix_poisson(coef[0] + ge, K);
+        else
+          so_local_matrix_elasticity(coef[0] + ge, coef[1] + ge, K);
+        for (int a = 0; a < 4; ++a)
+          for (int b = 0; b < 4; ++b)
+            {
+              const int ax = a & 1, ay = a >> 1, bx = b & 1, by = b >> 1;
+              const int node = (ex + ax) + (ey + ay) * npx;
+              const int dir  = (by - ay + 1) * 3 + (bx - ax + 1);
+              for (int ca = 0; ca < s; ++ca)
+                for (int cb = 0; cb < s; ++cb)
+                  ST(node, dir, ca, cb) += K[(4 * s) * (s * a + ca) + (s * b + cb)];
+            }
+      }
+}
+
+/* y = A x on the patch (unconstrained stencil), x,y [n_f_nodes*s][nv] row-major */
+static void stencil_apply_row(const so_patch *p, int s, const double *stencil, int ix, int iy,
+                              const double *x, int nv, double *yrow /* [s][nv] */)
+{
+  const int npx = p->nx + 1;
+  for (int i = 0; i < s * nv; ++i)
+    yrow[i] = 0.0;
+  const int node = ix + iy * npx;
+  for (int dy = -1; dy <= 1; ++dy)
+    for (int dx = -1; dx <= 1; ++dx)
+      {
+        const int jx = ix + dx, jy = iy + dy;
+        if (jx < 0 || jx > p->nx || jy < 0 || jy > p->ny)
+          continue;
+        const int nb  = jx + jy * npx;
+        const int dir = (dy + 1) * 3 + (dx + 1);
+        for (int a = 0; a < s; ++a)
+          for (int b = 0; b < s; ++b)
+            {
+              const double v = ST(node, dir, a, b);
+              if (v != 0.0)
+                for (int k = 0; k < nv; ++k)
+                  yrow[a * nv + k] += v * x[((size_t)nb * s + b) * nv + k];
+            }
+      }
+}
+
+/* ------------------------------------------------------------------------- */
+/* projection P^T (LODtools.h:7-73, LOD.cc:329-342,471-496)                  */
+/* ------------------------------------------------------------------------- */
+/* calls f(ctx, dof, column, value) for every non-zero of the UNZEROED PT. */
+typedef void (*pt_visit)(void *ctx, int dof, int col, double val);
+
+static void pt_foreach(const so_cfg *cfg, const so_patch *p, pt_visit f, void *ctx)
+{
+  const int    N = so_num_cells_per_side(cfg), n = cfg->n_sub, s = cfg->spacedim;
+  const double H = 1.0 / (double)N, h = H / (double)n, scale = h * h / 4.0;
+  const int    npx = p->nx + 1;
+  int          cells[4096];
+  const int    nc = so_patch_cells(cfg, p, cells);
+  for (int k = 0; k < nc; ++k)
+    {
+      const int kx = cells[k] % N - p->x0, ky = cells[k] / N - p->y0;
+      if (s == 2 && cfg->proj_quirk)
+        {
+          /* FESystem(FE_Q_iso_Q1(n),2) cell-local rows: vertices [c0,c1] x4, lines
+           * [c0 x (n-1), c1 x (n-1)] x4, quad [c0 x (n-1)^2, c1 x (n-1)^2]; the reference
+           * puts row r into column r%2 (LODtools.h:43-67). */
+          int r = 0;
+          for (int v = 0; v < 4; ++v)
+            for (int c = 0; c < 2; ++c, ++r)
+              {
+                const int ix = kx * n + (v & 1) * n, iy = ky * n + (v >> 1) * n;
+                f(ctx, 2 * (ix + iy * npx) + c, 2 * k + (r & 1), 1.0 * scale);
+              }
+          for (int L = 0; L < 4; ++L)
+            for (int c = 0; c < 2; ++c)
+              for (int t = 0; t < n - 1; ++t, ++r)
+                {
+                  int ix, iy;
+                  if (L == 0)
+                    ix = 0, iy = t + 1;
+                  else if (L == 1)
+                    ix = n, iy = t + 1;
+                  else if (L == 2)
+                    ix = t + 1, iy = 0;
+                  else
+                    ix = t + 1, iy = n;
+                  ix += kx * n;
+                  iy += ky * n;
+                  f(ctx, 2 * (ix + iy * npx) + c, 2 * k + (r & 1), 2.0 * scale);
+                }
+          for (int c = 0; c < 2; ++c)
+            for (int t = 0; t < (n - 1) * (n - 1); ++t, ++r)
+              {
+                const int ix = kx * n + 1 + t % (n - 1), iy = ky * n + 1 + t / (n - 1);
+                f(ctx, 2 * (ix + iy * npx) + c, 2 * k + (r & 1), 4.0 * scale);
+              }
+          continue;
+        }
+      for (int jy = 0; jy <= n; ++jy)
+        for (int jx = 0; jx <= n; ++jx)
+          {
+            const double w = ((jx == 0 || jx == n) ? 1.0 : 2.0) * ((jy == 0 || jy == n) ? 1.0 : 2.0);
+            const int    node = (kx * n + jx) + (ky * n + jy) * npx;
+            for (int c = 0; c < s; ++c)
+              f(ctx, s * node + c, s * k + c, w * scale);
+          }
+    }
+}
+
+static int node_is_boundary(const so_patch *p, int ix, int iy)
+{
+  return ix == 0 || ix == p->nx || iy == 0 || iy == p->ny;
+}
+static int node_on_domain(const so_patch *p, int ix, int iy)
+{
+  return (ix == 0 && p->side_domain[0]) || (ix == p->nx && p->side_domain[1]) ||
+         (iy == 0 && p->side_domain[2]) || (iy == p->ny && p->side_domain[3]);
+}
+static int node_on_99(const so_patch *p, int ix, int iy)
+{
+  return (ix == 0 && !p->side_domain[0]) || (ix == p->nx && !p->side_domain[1]) ||
+         (iy == 0 && !p->side_domain[2]) || (iy == p->ny && !p->side_domain[3]);
+}
+
+/* ------------------------------------------------------------------------- */
+/* constrained solve (LOD.cc:537-546, LODtools.h:511-595)                    */
+/* ------------------------------------------------------------------------- */
+/* interior dof -> band index; lines run along the shorter side */
+static int band_index(int nx, int ny, int s, int ix, int iy, int c)
+{
+  if (nx <= ny)
+    return s * ((ix - 1) + (iy - 1) * (nx - 1)) + c;
+  return s * ((iy - 1) + (ix - 1) * (ny - 1)) + c;
+}
+
+int so_solve_interior(int nx, int ny, int s, const double *stencil, const double *rhs, int nrhs,
+                      double *out)
+{
+  const int    npx = nx + 1;
+  const int    ni  = s * (nx - 1) * (ny - 1);
+  const int    ml  = (nx <= ny ? nx : ny) - 1;
+  const int    bw  = s * (ml + 1) + (s - 1);
+  const size_t ld  = (size_t)bw + 1;
+  double      *AB  = (double *)calloc((size_t)ni * ld, sizeof(double));
+  double      *Y   = (double *)malloc(sizeof(double) * (size_t)ni * (size_t)nrhs);
+  if (!AB || !Y)
+    return -1;
+  memset(out, 0, sizeof(double) * (size_t)s * npx * (ny + 1) * nrhs);
+  /* lower band of A_II: AB[j*ld + (i-j)] = A[i][j], i >= j */
+  for (int iy = 1; iy < ny; ++iy)
+    for (int ix = 1; ix < nx; ++ix)
+      for (int a = 0; a < s; ++a)
+        {
+          const int i = band_index(nx, ny, s, ix, iy, a);
+          for (int k = 0; k < nrhs; ++k)
+            Y[(size_t)i * nrhs + k] = rhs[((size_t)(ix + iy * npx) * s + a) * nrhs + k];
+          for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx)
+              {
+                const int jx = ix + dx, jy = iy + dy;
+                if (jx < 1 || jx >= nx || jy < 1 || jy >= ny)
+                  continue;
+                for (int b = 0; b < s; ++b)
+                  {
+                    const int j = band_index(nx, ny, s, jx, jy, b);
+                    if (j > i)
+                      continue;
+                    AB[(size_t)j * ld + (size_t)(i - j)] =
+                      ST(ix + iy * npx, (dy + 1) * 3 + (dx + 1), a, b);
+                  }
+              }
+        }
+  /* banded Cholesky A = L L^T */
+  for (int j = 0; j < ni; ++j)
+    {
+      double *cj = AB + (size_t)j * ld;
+      if (!(cj[0] > 0.0))
+        {
+          free(AB);
+          free(Y);
+          return -2;
+        }
+      const double d = sqrt(cj[0]);
+      cj[0]          = d;
+      const int kmax = imin(bw, ni - 1 - j);
+      const double r = 1.0 / d;
+      for (int k = 1; k <= kmax; ++k)
+        cj[k] *= r;
+      for (int k = 1; k <= kmax; ++k)
+        {
+          const double ljk = cj[k];
+          if (ljk == 0.0)
+            continue;
+          double *ck = AB + (size_t)(j + k) * ld;
+          for (int i = k; i <= kmax; ++i)
+            ck[i - k] -= cj[i] * ljk;
+        }
+    }
+  /* forward / backward substitution, all RHS at once (LODtools.h:533-571) */
+  for (int j = 0; j < ni; ++j)
+    {
+      const double *cj   = AB + (size_t)j * ld;
+      const int     kmax = imin(bw, ni - 1 - j);
+      double       *yj   = Y + (size_t)j * nrhs;
+      const double  r    = 1.0 / cj[0];
+      for (int k = 0; k < nrhs; ++k)
+        yj[k] *= r;
+      for (int i = 1; i <= kmax; ++i)
+        {
+          const double l = cj[i];
+          if (l == 0.0)
+            continue;
+          double *yi = Y + (size_t)(j + i) * nrhs;
+          for (int k = 0; k < nrhs; ++k)
+            yi[k] -= l * yj[k];
+        }
+    }
+  for (int j = ni - 1; j >= 0; --j)
+    {
+      const double *cj   = AB + (size_t)j * ld;
+      const int     kmax = imin(bw, ni - 1 - j);
+      double       *yj   = Y + (size_t)j * nrhs;
+      for (int i = 1; i <= kmax; ++i)
+        {
+          const double l = cj[i];
+          if (l == 0.0)
+            continue;
+          const double *yi = Y + (size_t)(j + i) * nrhs;
+          for (int k = 0; k < nrhs; ++k)
+            yj[k] -= l * yi[k];
+        }
+      const double r = 1.0 / cj[0];
+      for (int k = 0; k < nrhs; ++k)
+        yj[k] *= r;
+    }
+  for (int iy = 1; iy < ny; ++iy)
+    for (int ix = 1; ix < nx; ++ix)
+      for (int a = 0; a < s; ++a)
+        {
+          const int i = band_index(nx, ny, s, ix, iy, a);
+          for (int k = 0; k < nrhs; ++k)
+            out[((size_t)(ix + iy * npx) * s + a) * nrhs + k] = Y[(size_t)i * nrhs + k];
+        }
+  free(AB);
+  free(Y);
+  return 0;
+}
+
+typedef struct
+{
+  double       *PT;
+  int           nc;
+  const so_patch *p;
+  int           s;
+} pt_dense_ctx;
+
+static void pt_dense_visit(void *c, int dof, int col, double val)
+{
+  pt_dense_ctx *ctx = (pt_dense_ctx *)c;
+  ctx->PT[(size_t)dof * ctx->nc + col] += val;
+}
+
+int so_patch_solve(const so_cfg *cfg, const so_patch *p, const double *stencil, double *X)
+{
+  const int s  = cfg->spacedim;
+  double   *PT = (double *)calloc((size_t)p->n_f * p->n_c, sizeof(double));
+  if (!PT)
+    return -1;
+  pt_dense_ctx ctx = {PT, p->n_c, p, s};
+  pt_foreach(cfg, p, pt_dense_visit, &ctx);
+  /* boundary rows are ignored by so_solve_interior == zeroed rows (LOD.cc:512-518) */
+  const int rc = so_solve_interior(p->nx, p->ny, s, stencil, PT, p->n_c, X);
+  free(PT);
+  return rc;
+}
+
+/* ------------------------------------------------------------------------- */
+/* small dense helpers                                                       */
+/* ------------------------------------------------------------------------- */
+/* FullMatrix::gauss_jordan (LOD.cc:553): in-place inverse, partial pivoting */
+static int dense_inverse(int n, double *A)
+{
+  int *piv = (int *)malloc(sizeof(int) * (size_t)n);
+  for (int k = 0; k < n; ++k)
+    {
+      int    r   = k;
+      double big = fabs(A[k * n + k]);
+      for (int i = k + 1; i < n; ++i)
+        if (fabs(A[i * n + k]) > big)
+          big = fabs(A[i * n + k]), r = i;
+      if (big == 0.0)
+        {
+          free(piv);
+          return -1;
+        }
+      piv[k] = r;
+      if (r != k)
+        for (int j = 0; j < n; ++j)
+          {
+            const double t = A[k * n + j];
+            A[k * n + j]   = A[r * n + j];
+            A[r * n + j]   = t;
+          }
+      const double pinv = 1.0 / A[k * n + k];
+      A[k * n + k]      = 1.0;
+      for (int j = 0; j < n; ++j)
+        A[k * n + j] *= pinv;
+      for (int i = 0; i < n; ++i)
+        if (i != k)
+          {
+            const double f = A[i * n + k];
+            A[i * n + k]   = 0.0;
+            for (int j = 0; j < n; ++j)
+              A[i * n + j] -= f * A[k * n + j];
+          }
+    }
+  for (int k = n - 1; k >= 0; --k)
+    if (piv[k] != k)
+      for (int i = 0; i < n; ++i)
+        {
+          const double t    = A[i * n + k];
+          A[i * n + k]      = A[i * n + piv[k]];
+          A[i * n + piv[k]] = t;
+        }
+  free(piv);
+  return 0;
+}
+
+/* one-sided (Hestenes) Jacobi: W (m x n, row-major) is rotated in place until its columns
+ * are mutually orthogonal, V (n x n) accumulates the rotations: W_out = W_in V. */
+static void jacobi_one_sided(int m, int n, double *W, double *V)
+{
+  for (int i = 0; i < n * n; ++i)
+    V[i] = 0.0;
+  for (int i = 0; i < n; ++i)
+    V[i * n + i] = 1.0;
+  for (int sweep = 0; sweep < 60; ++sweep)
+    {
+      int rotated = 0;
+      for (int p = 0; p < n - 1; ++p)
+        for (int q = p + 1; q < n; ++q)
+          {
+            double app = 0, aqq = 0, apq = 0;
+            for (int i = 0; i < m; ++i)
+              {
+                const double wp = W[i * n + p], wq = W[i * n + q];
+                app += wp * wp;
+                aqq += wq * wq;
+                apq += wp * wq;
+              }
+            if (apq == 0.0 || fabs(apq) <= 1e-17 * sqrt(app * aqq))
+              continue;
+            rotated          = 1;
+            const double zeta = (aqq - app) / (2.0 * apq);
+            const double t    = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+            for (int i = 0; i < m; ++i)
+              {
+                const double wp = W[i * n + p], wq = W[i * n + q];
+                W[i * n + p]    = c * wp - sn * wq;
+                W[i * n + q]    = sn * wp + c * wq;
+              }
+            for (int i = 0; i < n; ++i)
+              {
+                const double vp = V[i * n + p], vq = V[i * n + q];
+                V[i * n + p]    = c * vp - sn * vq;
+                V[i * n + q]    = sn * vp + c * vq;
+              }
+          }
+      if (!rotated)
+        break;
+    }
+}
+
+/* two-sided cyclic Jacobi for a symmetric matrix: G -> diag, V eigenvectors */
+static void jacobi_eigen(int n, double *G, double *V)
+{
+  for (int i = 0; i < n * n; ++i)
+    V[i] = 0.0;
+  for (int i = 0; i < n; ++i)
+    V[i * n + i] = 1.0;
+  for (int sweep = 0; sweep < 100; ++sweep)
+    {
+      double off = 0, dia = 0;
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j)
+          {
+            if (i == j)
+              dia += G[i * n + j] * G[i * n + j];
+            else
+              off += G[i * n + j] * G[i * n + j];
+          }
+      if (off <= 1e-34 * dia)
+        break;
+      for (int p = 0; p < n - 1; ++p)
+        for (int q = p + 1; q < n; ++q)
+          {
+            const double apq = G[p * n + q];
+            if (apq == 0.0)
+              continue;
+            const double zeta = (G[q * n + q] - G[p * n + p]) / (2.0 * apq);
+            const double t    = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
+            for (int k = 0; k < n; ++k)
+              {
+                const double gkp = G[k * n + p], gkq = G[k * n + q];
+                G[k * n + p]     = c * gkp - sn * gkq;
+                G[k * n + q]     = sn * gkp + c * gkq;
+              }
+            for (int k = 0; k < n; ++k)
+              {
+                const double gpk = G[p * n + k], gqk = G[q * n + k];
+                G[p * n + k]     = c * gpk - sn * gqk;
+                G[q * n + k]     = sn * gpk + c * gqk;
+              }
+            for (int k = 0; k < n; ++k)
+              {
+                const double vp = V[k * n + p], vq = V[k * n + q];
+                V[k * n + p]    = c * vp - sn * vq;
+                V[k * n + q]    = sn * vp + c * vq;
+              }
+          }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* the per-patch pipeline (LOD.cc:345-767)                                   */
+/* ------------------------------------------------------------------------- */
+typedef struct
+{
+  double *M, *D, *BD, *X;
+  int    *bdofs;
+} so_dbg;
+
+static int patch_pipeline(const so_cfg *cfg, const double *const *coef, int pid, double *phi,
+                          double *psi, so_diag *diag, so_dbg *dbg)
+{
+  const int N = so_num_cells_per_side(cfg), s = cfg->spacedim;
+  so_patch  p;
+  so_patch_init(cfg, pid, &p);
+  const int    nf = p.n_f, nc = p.n_c, nb = p.n_b, npx = p.nx + 1;
+  const double H  = 1.0 / (double)N;
+  int          rc = 0;
+
+  double *stencil = (double *)malloc(sizeof(double) * (size_t)(nf / s) * 9 * s * s);
+  double *X       = (double *)malloc(sizeof(double) * (size_t)nf * nc);
+  double *PT      = (double *)calloc((size_t)nf * nc, sizeof(double));
+  double *M       = (double *)calloc((size_t)nc * nc, sizeof(double));
+  double *D       = (double *)malloc(sizeof(double) * (size_t)nc * nc);
+  double *BD      = (double *)calloc((size_t)(nb > 0 ? nb : 1) * nc, sizeof(double));
+  int    *bdofs   = (int *)malloc(sizeof(int) * (size_t)(nb > 0 ? nb : 1));
+  double *cvec    = (double *)malloc(sizeof(double) * (size_t)nc);
+  double *gam     = (double *)malloc(sizeof(double) * (size_t)nc);
+  if (!stencil || !X || !PT || !M || !D || !BD || !bdofs || !cvec || !gam)
+    return -1;
+
+  so_assemble_patch(cfg, &p, coef, stencil);                        /* LOD.cc:433-451 */
+  pt_dense_ctx ctx = {PT, nc, &p, s};
+  pt_foreach(cfg, &p, pt_dense_visit, &ctx);                        /* LOD.cc:471-496 */
+  rc = so_solve_interior(p.nx, p.ny, s, stencil, PT, nc, X);        /* LOD.cc:512-546 */
+  if (rc)
+    goto done;
+
+  /* M = PT^T X / H^dim with boundary rows of PT zeroed (LOD.cc:512-518,548-551):
+   * X is zero on those rows, so the unzeroed PT gives the same product. */
+  for (int i = 0; i < nf; ++i)
+    for (int a = 0; a < nc; ++a)
+      {
+        const double pv = PT[(size_t)i * nc + a];
+        if (pv != 0.0)
+          for (int b = 0; b < nc; ++b)
+            M[a * nc + b] += pv * X[(size_t)i * nc + b];
+      }
+  for (int i = 0; i < nc * nc; ++i)
+    M[i] /= (H * H);
+  memcpy(D, M, sizeof(double) * (size_t)nc * nc);
+  rc = dense_inverse(nc, D);                                        /* LOD.cc:553 */
+  if (rc)
+    goto done;
+
+  /* boundary (id 99) dofs in ascending order (LODtools.h:360-371) */
+  {
+    int k = 0;
+    for (int iy = 0; iy <= p.ny; ++iy)
+      for (int ix = 0; ix <= p.nx; ++ix)
+        if (node_on_99(&p, ix, iy))
+          for (int a = 0; a < s; ++a)
+            bdofs[k++] = s * (ix + iy * npx) + a;
+  }
+
+  if (!p.is_lod)
+    {
+      /* BD = (S_BI X_I - PT_B) D  (LOD.cc:609-618) */
+      double *Bf   = (double *)malloc(sizeof(double) * (size_t)nb * nc);
+      double *yrow = (double *)malloc(sizeof(double) * (size_t)s * nc);
+      for (int k = 0; k < nb; k += s)
+        {
+          const int node = bdofs[k] / s, ix = node % npx, iy = node / npx;
+          stencil_apply_row(&p, s, stencil, ix, iy, X, nc, yrow);
+          for (int a = 0; a < s; ++a)
+            for (int c = 0; c < nc; ++c)
+              Bf[(size_t)(k + a) * nc + c] = yrow[a * nc + c] - PT[(size_t)bdofs[k + a] * nc + c];
+        }
+      for (int k = 0; k < nb; ++k)
+        for (int c = 0; c < nc; ++c)
+          {
+            double acc = 0;
+            for (int j = 0; j < nc; ++j)
+              acc += Bf[(size_t)k * nc + j] * D[j * nc + c];
+            BD[(size_t)k * nc + c] = acc;
+          }
+      free(Bf);
+      free(yrow);
+    }
+
+  for (int d = 0; d < s; ++d)
+    {
+      for (int i = 0; i < nc; ++i)
+        gam[i] = 0.0;
+      gam[d] = 1.0;
+      if (!p.is_lod)
+        {
+          /* least squares d = -(BD'^T BD')^+ BD'^T b0 with the 0.5-loop (LOD.cc:620-725) */
+          const int nn    = nc - 1;
+          double   *W     = (double *)malloc(sizeof(double) * (size_t)nb * nn);
+          double   *V     = (double *)malloc(sizeof(double) * (size_t)nn * nn);
+          double   *sig   = (double *)malloc(sizeof(double) * (size_t)nn);
+          double   *utg   = (double *)malloc(sizeof(double) * (size_t)nn);
+          double   *del   = (double *)calloc((size_t)nn, sizeof(double));
+          int      *order = (int *)malloc(sizeof(int) * (size_t)nn);
+          for (int i = 0; i < nb; ++i)
+            for (int j = 0, jj = 0; j < nc; ++j)
+              if (j != d)
+                W[(size_t)i * nn + jj++] = BD[(size_t)i * nc + j];
+          if (g_svd_mode == 0)
+            {
+              jacobi_one_sided(nb, nn, W, V);
+              for (int j = 0; j < nn; ++j)
+                {
+                  double ss = 0, wb = 0;
+                  for (int i = 0; i < nb; ++i)
+                    {
+                      ss += W[(size_t)i * nn + j] * W[(size_t)i * nn + j];
+                      wb += W[(size_t)i * nn + j] * BD[(size_t)i * nc + d];
+                    }
+                  sig[j] = ss;  /* singular value of G */
+                  utg[j] = wb;  /* u_j^T g            */
+                }
+            }
+          else
+            {
+              double *G = (double *)calloc((size_t)nn * nn, sizeof(double));
+              double *g = (double *)calloc((size_t)nn, sizeof(double));
+              for (int i = 0; i < nb; ++i)
+                for (int a = 0; a < nn; ++a)
+                  {
+                    const double wa = W[(size_t)i * nn + a];
+                    g[a] += wa * BD[(size_t)i * nc + d];
+                    for (int b = 0; b < nn; ++b)
+                      G[a * nn + b] += wa * W[(size_t)i * nn + b];
+                  }
+              jacobi_eigen(nn, G, V);
+              for (int j = 0; j < nn; ++j)
+                {
+                  sig[j] = G[j * nn + j];
+                  double t = 0;
+                  for (int a = 0; a < nn; ++a)
+                    t += V[a * nn + j] * g[a];
+                  utg[j] = t;
+                }
+              free(G);
+              free(g);
+            }
+          for (int j = 0; j < nn; ++j)
+            order[j] = j;
+          for (int a = 1; a < nn; ++a) /* descending sigma */
+            {
+              const int o = order[a];
+              int       b = a - 1;
+              while (b >= 0 && sig[order[b]] < sig[o])
+                order[b + 1] = order[b], --b;
+              order[b + 1] = o;
+            }
+          const double s0  = sig[order[0]];
+          int          cut = 0, dropped = 0;
+          for (int r = 0; r < nn; ++r)
+            {
+              const int j = order[r];
+              if (sig[j] > 1e-15 * s0) /* compute_inverse_svd(1e-15), LOD.cc:667 */
+                utg[j] = utg[j] / sig[j];
+              else
+                utg[j] = 0.0, ++cut;
+              for (int a = 0; a < nn; ++a)
+                del[a] -= V[a * nn + j] * utg[j];
+            }
+          double dinf = 0;
+          for (int r = nn - 1; r >= 0; --r) /* LOD.cc:703-725 */
+            {
+              dinf = 0;
+              for (int a = 0; a < nn; ++a)
+                dinf = fmax(dinf, fabs(del[a]));
+              if (dinf < 0.5)
+                break;
+              const int j = order[r];
+              for (int a = 0; a < nn; ++a)
+                del[a] += V[a * nn + j] * utg[j];
+              ++dropped;
+            }
+          dinf = 0;
+          for (int a = 0; a < nn; ++a)
+            dinf = fmax(dinf, fabs(del[a]));
+          for (int j = 0, jj = 0; j < nc; ++j)
+            if (j != d)
+              gam[j] = del[jj++];
+          if (diag)
+            {
+              diag->n_dropped[d] = dropped;
+              diag->n_cut[d]     = cut;
+              diag->dinf[d]      = dinf;
+              diag->sigma_max[d] = s0;
+              diag->sigma_min[d] = sig[order[nn - 1]];
+            }
+          free(W);
+          free(V);
+          free(sig);
+          free(utg);
+          free(del);
+          free(order);
+        }
+      else if (diag)
+        {
+          diag->n_dropped[d] = 0;
+          diag->n_cut[d]     = 0;
+          diag->dinf[d]      = 0;
+          diag->sigma_max[d] = diag->sigma_min[d] = 0;
+        }
+      /* c = D gamma (LOD.cc:727-743 / 576-577) */
+      for (int i = 0; i < nc; ++i)
+        {
+          double acc = 0;
+          for (int j = 0; j < nc; ++j)
+            acc += D[i * nc + j] * gam[j];
+          cvec[i] = acc;
+        }
+      /* phi = X c, zero on all boundary dofs (LOD.cc:745-750 / 587-588), normalise (:752/:591) */
+      double *ph = phi + (size_t)d * nf, *ps = psi + (size_t)d * nf;
+      double  nrm = 0;
+      for (int i = 0; i < nf; ++i)
+        {
+          double acc = 0;
+          for (int j = 0; j < nc; ++j)
+            acc += X[(size_t)i * nc + j] * cvec[j];
+          ph[i] = acc;
+          nrm += acc * acc;
+        }
+      nrm = sqrt(nrm);
+      for (int i = 0; i < nf; ++i)
+        ph[i] /= nrm;
+      /* psi = A_semi phi (LOD.cc:537-541,758-765) */
+      double yrow[2];
+      for (int iy = 0; iy <= p.ny; ++iy)
+        for (int ix = 0; ix <= p.nx; ++ix)
+          {
+            const int node = ix + iy * npx;
+            if (node_on_domain(&p, ix, iy))
+              {
+                for (int a = 0; a < s; ++a)
+                  ps[s * node + a] = ph[s * node + a];
+              }
+            else
+              {
+                stencil_apply_row(&p, s, stencil, ix, iy, ph, 1, yrow);
+                for (int a = 0; a < s; ++a)
+                  ps[s * node + a] = yrow[a];
+              }
+          }
+    }
+  (void)node_is_boundary;
+  if (dbg)
+    {
+      if (dbg->M)
+        memcpy(dbg->M, M, sizeof(double) * (size_t)nc * nc);
+      if (dbg->D)
+        memcpy(dbg->D, D, sizeof(double) * (size_t)nc * nc);
+      if (dbg->BD && nb > 0)
+        memcpy(dbg->BD, BD, sizeof(double) * (size_t)nb * nc);
+      if (dbg->bdofs && nb > 0)
+        memcpy(dbg->bdofs, bdofs, sizeof(int) * (size_t)nb);
+      if (dbg->X)
+        memcpy(dbg->X, X, sizeof(double) * (size_t)nf * nc);
+    }
+done:
+  free(stencil);
+  free(X);
+  free(PT);
+  free(M);
+  free(D);
+  free(BD);
+  free(bdofs);
+  free(cvec);
+  free(gam);
+  return rc;
+}
+
+int so_patch_basis(const so_cfg *cfg, const double *const *coef, int pid, double *phi, double *psi,
+                   so_diag *diag)
+{
+  return patch_pipeline(cfg, coef, pid, phi, psi, diag, NULL);
+}
+
+int so_patch_debug(const so_cfg *cfg, const double *const *coef, int pid, double *M, double *D,
+                   double *BD, int *bdofs, double *X)
+{
+  so_patch p;
+  so_patch_init(cfg, pid, &p);
+  double *phi = (double *)malloc(sizeof(double) * (size_t)p.n_f * cfg->spacedim);
+  double *psi = (double *)malloc(sizeof(double) * (size_t)p.n_f * cfg->spacedim);
+  so_dbg  dbg = {M, D, BD, X, bdofs};
+  const int rc = patch_pipeline(cfg, coef, pid, phi, psi, NULL, &dbg);
+  free(phi);
+  free(psi);
+  return rc;
+}
+
+int so_basis_many(const so_cfg *cfg, const double *const *coef, const int *ids, int n, double *phi,
+                  double *psi, const long long *offsets, int nthreads)
+{
+  const int s = cfg->spacedim, full = 2 * cfg->oversampling + 1;
+  const long long stride = (long long)s * s * (cfg->n_sub * full + 1) * (cfg->n_sub * full + 1);
+  int             err    = 0;
+#ifdef _OPENMP
+  if (nthreads < 1)
+    nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+#endif
+  for (int k = 0; k < n; ++k)
+    {
+      const long long off = offsets ? offsets[k] : stride * k;
+      const int rc = patch_pipeline(cfg, coef, ids[k], phi + off, psi + off, NULL, NULL);
+      if (rc)
+        {
+#ifdef _OPENMP
+#pragma omp atomic write
+#endif
+          err = rc;
+        }
+    }
+  (void)nthreads;
+  return err;
+}
+
+/* ------------------------------------------------------------------------- */
+/* synthetic coefficients                                                    */
+/* ------------------------------------------------------------------------- */
+static unsigned long long splitmix64(unsigned long long *state)
+{
+  unsigned long long z = (*state += 0x9E3779B97F4A7C15ULL);
+  z                    = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z                    = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+
+void so_fill_coefficient(unsigned long long seed, int dist, double lo, double hi,
+                         int n_elems_per_side, double *coef_qp)
+{
+  unsigned long long st = seed;
+  const size_t       ne = (size_t)n_elems_per_side * n_elems_per_side;
+  for (size_t e = 0; e < ne; ++e)
+    {
+      const double u = (double)(splitmix64(&st) >> 11) * (1.0 / 9007199254740992.0);
+      const double v = dist == 0 ? lo + (hi - lo) * u : lo * pow(hi / lo, u);
+      for (int q = 0; q < 4; ++q)
+        coef_qp[4 * e + q] = v;
+    }
+}
+
+void so_fill_coefficient_rand(double lo, double hi, int r, int n_elems_per_side, double *coef_qp)
+{
+  const int    NC   = 1 << r;
+  const size_t nv   = (size_t)NC * NC;
+  double      *vals = (double *)malloc(sizeof(double) * nv);
+  for (size_t i = 0; i < nv; ++i) /* Diffusion.h:30-36 */
+    vals[i] = lo + (double)((float)rand() / ((float)(RAND_MAX / (hi - lo))));
+  const double eta = 1.0 / (double)NC, hf = 1.0 / (double)n_elems_per_side;
+  for (int ey = 0; ey < n_elems_per_side; ++ey)
+    for (int ex = 0; ex < n_elems_per_side; ++ex)
+      for (int q = 0; q < 4; ++q)
+        {
+          double xi, et;
+          gauss_point(q, &xi, &et);
+          const double x = (ex + xi) * hf, y = (ey + et) * hf;
+          const int    idx = (int)floor(x / eta) + NC * (int)floor(y / eta); /* Diffusion.h:47-51 */
+          coef_qp[((size_t)ey * n_elems_per_side + ex) * 4 + q] = vals[idx];
+        }
+  free(vals);
+}
