@@ -1,0 +1,793 @@
+// Host side of libslod_hip.so: handle / plan management, patch index calculus, launches.
+// Implements include/slod.h.  No CPU fallback exists: every compute entry point needs a
+// HIP device and fails with SLOD_ERR_DEVICE otherwise.
+#include "../../include/slod.h"
+#include "slod_device.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace
+{
+  thread_local std::string g_create_error;
+
+  struct PatchGeom
+  {
+    int cx, cy, x0, y0, mx, my;
+    int side_domain[4];
+  };
+} // namespace
+
+struct slod_handle
+{
+  slod_config         cfg;
+  int                 N  = 0; // coarse cells per side
+  int                 NE = 0; // fine elements per side
+  int                 NP = 0; // patches per problem
+  int                 first_full = -1;
+  double             *d_coef[2]  = {nullptr, nullptr};
+  std::vector<char>   coef_set;  // [problem*2 + field]
+  hipStream_t         stream = nullptr;
+  mutable std::string error;
+};
+
+struct slod_plan
+{
+  slod_handle               *h = nullptr;
+  size_t                     n = 0;
+  std::vector<SlodPatchDesc> desc;
+  SlodPatchDesc             *d_desc = nullptr;
+  int                        m_max = 0, L_max = 0, nc_max = 0, nb_max = 0, nn_max = 0, nf_max = 0;
+  size_t                     stride = 0, out_size = 0;
+  size_t                     chunk = 0;
+  double                    *ws_st = nullptr, *ws_v = nullptr, *ws_x = nullptr;
+  size_t                     st_stride = 0, v_stride = 0, x_stride = 0;
+  int32_t                   *d_status = nullptr;
+  std::vector<hipEvent_t>    ev; // 4 per chunk
+  bool                       ran = false;
+};
+
+namespace
+{
+  int fail(const slod_handle *h, int code, const std::string &msg)
+  {
+    if (h)
+      h->error = msg;
+    else
+      g_create_error = msg;
+    return code;
+  }
+
+  int hip_fail(const slod_handle *h, hipError_t e, const char *what)
+  {
+    return fail(h, SLOD_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+  }
+
+  // Morton order of hyper_cube + refine_global (x in the even bits), or row-major for a
+  // non-2^k grid.  Reference: patches are stored in active-cell order (LOD.cc:184-192).
+  void patch_centre(const slod_handle *h, uint32_t pid, int &cx, int &cy)
+  {
+    if (h->cfg.n_cells_per_side > 0)
+      {
+        cx = (int)(pid % (uint32_t)h->N);
+        cy = (int)(pid / (uint32_t)h->N);
+        return;
+      }
+    cx = cy = 0;
+    for (int b = 0; b < h->cfg.n_global_refinements; ++b)
+      {
+        cx |= (int)((pid >> (2 * b)) & 1u) << b;
+        cy |= (int)((pid >> (2 * b + 1)) & 1u) << b;
+      }
+  }
+
+  // LOD.cc:140-181 (extent) and LOD.cc:830-843 (boundary ids of the four sides)
+  PatchGeom patch_geom(const slod_handle *h, uint32_t pid)
+  {
+    PatchGeom g;
+    const int l = h->cfg.oversampling, N = h->N;
+    patch_centre(h, pid, g.cx, g.cy);
+    g.x0         = std::max(g.cx - l, 0);
+    g.y0         = std::max(g.cy - l, 0);
+    const int x1 = std::min(g.cx + l, N - 1), y1 = std::min(g.cy + l, N - 1);
+    g.mx             = x1 - g.x0 + 1;
+    g.my             = y1 - g.y0 + 1;
+    g.side_domain[0] = (g.x0 == 0);
+    g.side_domain[1] = (x1 == N - 1);
+    g.side_domain[2] = (g.y0 == 0);
+    g.side_domain[3] = (y1 == N - 1);
+    return g;
+  }
+
+  void fill_info(const slod_handle *h, const PatchGeom &g, slod_patch_info *info)
+  {
+    const int n = h->cfg.n_subdivisions, s = h->cfg.spacedim;
+    info->cx = g.cx;
+    info->cy = g.cy;
+    info->x0 = g.x0;
+    info->y0 = g.y0;
+    info->mx = g.mx;
+    info->my = g.my;
+    info->nx = n * g.mx;
+    info->ny = n * g.my;
+    for (int i = 0; i < 4; ++i)
+      info->side_domain[i] = g.side_domain[i];
+    info->n_fine     = s * (info->nx + 1) * (info->ny + 1);
+    info->n_internal = s * (info->nx - 1) * (info->ny - 1);
+    info->n_coarse   = s * g.mx * g.my;
+    // id-99 nodes, corners shared with an id-0 side included (LODtools.h:367-369)
+    int nb = 0;
+    if (!g.side_domain[2])
+      nb += info->nx + 1;
+    else
+      nb += !g.side_domain[0] + !g.side_domain[1];
+    if (!g.side_domain[3])
+      nb += info->nx + 1;
+    else
+      nb += !g.side_domain[0] + !g.side_domain[1];
+    nb += (info->ny - 1) * (!g.side_domain[0] + !g.side_domain[1]);
+    info->n_boundary = s * nb;
+    info->is_lod     = (!h->cfg.lod_stabilization) || h->cfg.oversampling == 0 ||
+                   (g.mx * g.my == h->N * h->N);
+  }
+
+  bool is_full(const slod_handle *h, const PatchGeom &g)
+  {
+    const int f = 2 * h->cfg.oversampling + 1;
+    return g.mx == f && g.my == f;
+  }
+
+  SlodPatchDesc make_desc(const slod_handle *h, uint32_t gid)
+  {
+    const uint32_t  prob = gid / (uint32_t)h->NP, pid = gid % (uint32_t)h->NP;
+    const PatchGeom g = patch_geom(h, pid);
+    slod_patch_info info;
+    fill_info(h, g, &info);
+    const int     n = h->cfg.n_subdivisions, s = h->cfg.spacedim;
+    SlodPatchDesc d;
+    std::memset(&d, 0, sizeof(d));
+    d.ox = g.x0 * n;
+    d.oy = g.y0 * n;
+    if (h->cfg.constant_coefficients && is_full(h, g) && h->first_full >= 0)
+      {
+        // quirk Q1 (LOD.cc:354-362,446-450): later full patches copy the first one's matrix
+        const PatchGeom f = patch_geom(h, (uint32_t)h->first_full);
+        d.ox              = f.x0 * n;
+        d.oy              = f.y0 * n;
+      }
+    d.nx    = info.nx;
+    d.ny    = info.ny;
+    d.mx    = g.mx;
+    d.my    = g.my;
+    d.ccx   = g.cx - g.x0;
+    d.ccy   = g.cy - g.y0;
+    d.flags = (g.side_domain[0] ? 1 : 0) | (g.side_domain[1] ? 2 : 0) | (g.side_domain[2] ? 4 : 0) |
+              (g.side_domain[3] ? 8 : 0);
+    if (info.is_lod)
+      d.flags |= SLOD_F_LOD;
+    if (info.nx > info.ny)
+      {
+        d.flags |= SLOD_F_TRANSPOSED;
+        d.m = s * (info.ny - 1);
+        d.L = info.nx - 1;
+      }
+    else
+      {
+        d.m = s * (info.nx - 1);
+        d.L = info.ny - 1;
+      }
+    d.n_c  = info.n_coarse;
+    d.n_b  = info.n_boundary;
+    d.prob = (int32_t)prob;
+    return d;
+  }
+
+  // stream + coefficient storage; called by every entry point that touches the device
+  int ensure_device(slod_handle *h)
+  {
+    if (h->stream)
+      return SLOD_OK;
+    hipError_t e = hipSetDevice(h->cfg.device);
+    if (e != hipSuccess)
+      return hip_fail(h, e, "hipSetDevice (no usable HIP device; this library has no CPU fallback)");
+    e = hipStreamCreate(&h->stream);
+    if (e != hipSuccess)
+      {
+        h->stream = nullptr;
+        return hip_fail(h, e, "hipStreamCreate");
+      }
+    const size_t bytes = (size_t)h->cfg.n_problems * h->NE * h->NE * 4 * sizeof(double);
+    for (int f = 0; f < h->cfg.spacedim; ++f)
+      {
+        e = hipMalloc((void **)&h->d_coef[f], bytes);
+        if (e != hipSuccess)
+          return hip_fail(h, e, "hipMalloc(coefficient field)");
+      }
+    return SLOD_OK;
+  }
+
+  SlodKernelArgs make_args(const slod_plan *p, size_t first, double *d_basis, double *d_premult)
+  {
+    const slod_handle *h = p->h;
+    SlodKernelArgs     a;
+    std::memset(&a, 0, sizeof(a));
+    a.desc        = p->d_desc + first;
+    a.coef0       = h->d_coef[0];
+    a.coef1       = h->d_coef[1];
+    a.coef_stride = (size_t)h->NE * h->NE * 4;
+    a.NE          = h->NE;
+    a.n_sub       = h->cfg.n_subdivisions;
+    a.quirk       = h->cfg.projection_quirk;
+    const double H = 1.0 / (double)h->N, hh = H / (double)h->cfg.n_subdivisions;
+    a.scale     = hh * hh / 4.0; // LOD.cc:341
+    a.invH2     = 1.0 / (H * H); // LOD.cc:551
+    a.st        = p->ws_st;
+    a.st_stride = p->st_stride;
+    a.nn_max    = p->nn_max;
+    a.vinv      = p->ws_v;
+    a.v_stride  = p->v_stride;
+    a.m_max     = p->m_max;
+    a.xs        = p->ws_x;
+    a.x_stride  = p->x_stride;
+    a.nc_max    = p->nc_max;
+    a.basis     = d_basis;
+    a.premult   = d_premult;
+    a.status    = p->d_status;
+    return a;
+  }
+} // namespace
+
+extern "C" {
+
+int slod_abi_version(void) { return SLOD_ABI_VERSION; }
+
+const char *slod_last_error(const slod_handle *h)
+{
+  return h ? h->error.c_str() : g_create_error.c_str();
+}
+
+int slod_create(const slod_config *cfg, slod_handle **out)
+{
+  if (!cfg || !out)
+    return fail(nullptr, SLOD_ERR_ARGUMENT, "slod_create: null argument");
+  *out = nullptr;
+  if (cfg->dim != 2)
+    return fail(nullptr, SLOD_ERR_UNSUPPORTED, "slod_create: only dim == 2 (reference LOD.cc:1470-1471)");
+  if (cfg->spacedim != 1 && cfg->spacedim != 2)
+    return fail(nullptr, SLOD_ERR_UNSUPPORTED, "slod_create: spacedim must be 1 or 2");
+  if (cfg->n_subdivisions < 1 || cfg->oversampling < 0 || cfg->n_global_refinements < 0 ||
+      cfg->n_global_refinements > 14 || cfg->n_cells_per_side < 0 || cfg->n_problems < 1)
+    return fail(nullptr, SLOD_ERR_ARGUMENT, "slod_create: parameter out of range");
+  slod_handle *h = new slod_handle;
+  h->cfg         = *cfg;
+  h->N           = cfg->n_cells_per_side > 0 ? cfg->n_cells_per_side : (1 << cfg->n_global_refinements);
+  h->NE          = h->N * cfg->n_subdivisions;
+  h->NP          = h->N * h->N;
+  if ((uint64_t)h->NP * (uint64_t)cfg->n_problems > 0xffffffffull)
+    {
+      delete h;
+      return fail(nullptr, SLOD_ERR_ARGUMENT, "slod_create: too many patches for 32-bit ids");
+    }
+  for (int pid = 0; pid < h->NP; ++pid)
+    if (is_full(h, patch_geom(h, (uint32_t)pid)))
+      {
+        h->first_full = pid;
+        break;
+      }
+  h->coef_set.assign((size_t)cfg->n_problems * 2, 0);
+  // device resources are created lazily (ensure_device): the index calculus below works
+  // without a GPU, every compute entry point needs one.
+  *out = h;
+  return SLOD_OK;
+}
+
+void slod_destroy(slod_handle *h)
+{
+  if (!h)
+    return;
+  for (int f = 0; f < 2; ++f)
+    if (h->d_coef[f])
+      (void)hipFree(h->d_coef[f]);
+  if (h->stream)
+    (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int slod_num_patches(const slod_handle *h) { return h ? h->NP : SLOD_ERR_ARGUMENT; }
+
+int slod_patch_layout(const slod_handle *h, uint32_t patch_id, slod_patch_info *info)
+{
+  if (!h || !info)
+    return SLOD_ERR_ARGUMENT;
+  if (patch_id >= (uint32_t)h->NP)
+    return fail(h, SLOD_ERR_ARGUMENT, "slod_patch_layout: patch id out of range");
+  fill_info(h, patch_geom(h, patch_id), info);
+  return SLOD_OK;
+}
+
+int slod_patch_cells(const slod_handle *h, uint32_t patch_id, uint32_t *cells, size_t capacity)
+{
+  if (!h || !cells)
+    return SLOD_ERR_ARGUMENT;
+  if (patch_id >= (uint32_t)h->NP)
+    return fail(h, SLOD_ERR_ARGUMENT, "slod_patch_cells: patch id out of range");
+  const PatchGeom g = patch_geom(h, patch_id);
+  if (capacity < (size_t)(g.mx * g.my))
+    return fail(h, SLOD_ERR_ARGUMENT, "slod_patch_cells: buffer too small");
+  const int l = h->cfg.oversampling, N = h->N;
+  size_t    c = 0;
+  cells[c++]  = (uint32_t)(g.cx + N * g.cy); // LOD.cc:151-154
+  for (int lr = -l; lr <= l; ++lr)           // LOD.cc:156-178
+    {
+      const int x = g.cx + lr;
+      if (x < 0 || x >= N)
+        continue;
+      for (int lc = -l; lc <= l; ++lc)
+        {
+          const int y = g.cy + lc;
+          if (y < 0 || y >= N || (lr == 0 && lc == 0))
+            continue;
+          cells[c++] = (uint32_t)(x + N * y);
+        }
+    }
+  return (int)c;
+}
+
+int slod_patch_dof_permutation(const slod_handle *h, uint32_t patch_id, uint32_t *perm, size_t capacity)
+{
+  if (!h || !perm)
+    return SLOD_ERR_ARGUMENT;
+  if (patch_id >= (uint32_t)h->NP)
+    return fail(h, SLOD_ERR_ARGUMENT, "slod_patch_dof_permutation: patch id out of range");
+  const PatchGeom g = patch_geom(h, patch_id);
+  slod_patch_info info;
+  fill_info(h, g, &info);
+  if (capacity < (size_t)info.n_fine)
+    return fail(h, SLOD_ERR_ARGUMENT, "slod_patch_dof_permutation: buffer too small");
+  const int             n = h->cfg.n_subdivisions, s = h->cfg.spacedim, npx = info.nx + 1, N = h->N;
+  std::vector<uint32_t> cells((size_t)g.mx * g.my);
+  slod_patch_cells(h, patch_id, cells.data(), cells.size());
+  std::vector<int32_t> number((size_t)info.n_fine, -1);
+  uint32_t             next  = 0;
+  auto                 touch = [&](int ix, int iy, int c) {
+    const int lex = s * (ix + iy * npx) + c;
+    if (number[lex] < 0)
+      {
+        number[lex]  = (int32_t)next;
+        perm[next++] = (uint32_t)lex;
+      }
+  };
+  // DoFHandler::distribute_dofs on the patch sub-triangulation: cells in creation order
+  // (= patch->cells, LOD.cc:803-819), per cell vertex, line, quad dofs, first touch;
+  // FESystem keeps the component copies of one geometric object consecutive.
+  for (uint32_t cell : cells)
+    {
+      const int bx = ((int)(cell % (uint32_t)N) - g.x0) * n, by = ((int)(cell / (uint32_t)N) - g.y0) * n;
+      for (int v = 0; v < 4; ++v)
+        for (int c = 0; c < s; ++c)
+          touch(bx + (v & 1) * n, by + (v >> 1) * n, c);
+      for (int line = 0; line < 4; ++line)
+        for (int c = 0; c < s; ++c)
+          for (int t = 1; t < n; ++t)
+            {
+              if (line == 0)
+                touch(bx, by + t, c);
+              else if (line == 1)
+                touch(bx + n, by + t, c);
+              else if (line == 2)
+                touch(bx + t, by, c);
+              else
+                touch(bx + t, by + n, c);
+            }
+      for (int c = 0; c < s; ++c)
+        for (int jy = 1; jy < n; ++jy)
+          for (int jx = 1; jx < n; ++jx)
+            touch(bx + jx, by + jy, c);
+    }
+  return (int)next;
+}
+
+int slod_partition(uint64_t n_total, uint32_t n_ranks, uint32_t rank, uint64_t *begin, uint64_t *end)
+{
+  if (!begin || !end || n_ranks == 0 || rank >= n_ranks)
+    return SLOD_ERR_ARGUMENT;
+  // Utilities::MPI::create_evenly_distributed_partitioning: the first (n % p) ranks own
+  // one element more.
+  const uint64_t q = n_total / n_ranks, r = n_total % n_ranks;
+  *begin = (uint64_t)rank * q + std::min<uint64_t>(rank, r);
+  *end   = *begin + q + (rank < r ? 1 : 0);
+  return SLOD_OK;
+}
+
+int slod_set_coefficient(slod_handle *h, uint32_t problem, int field, const double *data, int layout,
+                         size_t count, int on_device)
+{
+  if (!h || !data)
+    return SLOD_ERR_ARGUMENT;
+  if (problem >= (uint32_t)h->cfg.n_problems || field < 0 || field >= h->cfg.spacedim)
+    return fail(h, SLOD_ERR_ARGUMENT, "slod_set_coefficient: problem/field out of range");
+  const size_t ne = (size_t)h->NE * h->NE;
+  if ((layout == 0 && count != ne) || (layout == 1 && count != 4 * ne) || (layout != 0 && layout != 1))
+    return fail(h, SLOD_ERR_ARGUMENT, "slod_set_coefficient: wrong element count for layout");
+  if (const int rc = ensure_device(h))
+    return rc;
+  (void)hipSetDevice(h->cfg.device);
+  double    *dst = h->d_coef[field] + (size_t)problem * ne * 4;
+  hipError_t e;
+  if (layout == 1)
+    e = hipMemcpyAsync(dst, data, 4 * ne * sizeof(double),
+                       on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream);
+  else if (on_device)
+    {
+      e = hipSuccess;
+      for (int q = 0; q < 4 && e == hipSuccess; ++q)
+        e = hipMemcpy2DAsync(dst + q, 4 * sizeof(double), data, sizeof(double), sizeof(double), ne,
+                             hipMemcpyDeviceToDevice, h->stream);
+    }
+  else
+    {
+      std::vector<double> tmp(4 * ne);
+      for (size_t i = 0; i < ne; ++i)
+        tmp[4 * i] = tmp[4 * i + 1] = tmp[4 * i + 2] = tmp[4 * i + 3] = data[i];
+      e = hipMemcpyAsync(dst, tmp.data(), 4 * ne * sizeof(double), hipMemcpyHostToDevice, h->stream);
+      if (e == hipSuccess)
+        e = hipStreamSynchronize(h->stream);
+    }
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess)
+    return hip_fail(h, e, "slod_set_coefficient");
+  h->coef_set[(size_t)problem * 2 + field] = 1;
+  return SLOD_OK;
+}
+
+int slod_plan_create(slod_handle *h, const uint32_t *gids, size_t n, const uint64_t *offsets, slod_plan **out)
+{
+  if (!h || !out || (!gids && n))
+    return SLOD_ERR_ARGUMENT;
+  *out = nullptr;
+  if (const int rc = ensure_device(h))
+    return rc;
+  (void)hipSetDevice(h->cfg.device);
+  const uint64_t total = (uint64_t)h->NP * (uint64_t)h->cfg.n_problems;
+  slod_plan     *p     = new slod_plan;
+  p->h                 = h;
+  p->n                 = n;
+  p->desc.resize(n);
+  const int s = h->cfg.spacedim, n_sub = h->cfg.n_subdivisions, full = 2 * h->cfg.oversampling + 1;
+  // uniform stride = the full patch's s vectors of n_fine (what an all-gather slab uses)
+  p->stride = (size_t)s * s * (size_t)(n_sub * full + 1) * (size_t)(n_sub * full + 1);
+  for (size_t k = 0; k < n; ++k)
+    {
+      if (gids[k] >= total)
+        {
+          delete p;
+          return fail(h, SLOD_ERR_ARGUMENT, "slod_plan_create: patch id out of range");
+        }
+      SlodPatchDesc d = make_desc(h, gids[k]);
+      d.out_off       = offsets ? offsets[k] : (uint64_t)k * p->stride;
+      const int nn    = (d.nx + 1) * (d.ny + 1);
+      p->m_max        = std::max(p->m_max, (int)d.m);
+      p->L_max        = std::max(p->L_max, (int)d.L);
+      p->nc_max       = std::max(p->nc_max, (int)d.n_c);
+      p->nb_max       = std::max(p->nb_max, (d.flags & SLOD_F_LOD) ? 0 : (int)d.n_b);
+      p->nn_max       = std::max(p->nn_max, nn);
+      p->nf_max       = std::max(p->nf_max, s * nn);
+      p->out_size     = std::max(p->out_size, (size_t)d.out_off + (size_t)s * s * nn);
+      p->desc[k]      = d;
+    }
+  if (n == 0)
+    {
+      *out = p;
+      return SLOD_OK;
+    }
+  if (p->m_max > 16 * 7)
+    {
+      delete p;
+      return fail(h, SLOD_ERR_UNSUPPORTED, "slod_plan_create: more than 112 dofs per grid line");
+    }
+  if (p->nc_max > 64)
+    {
+      delete p;
+      return fail(h, SLOD_ERR_UNSUPPORTED, "slod_plan_create: more than 64 coarse dofs per patch");
+    }
+  hipError_t e = hipSuccess;
+  const size_t lds_max = 160 * 1024;
+  if (slod_solve_lds_bytes(s, p->m_max, p->nc_max) > lds_max ||
+      slod_select_lds_bytes(s, p->nb_max, p->nc_max, p->nf_max) > lds_max)
+    {
+      delete p;
+      return fail(h, SLOD_ERR_UNSUPPORTED, "slod_plan_create: patch does not fit the 160 KB LDS");
+    }
+  p->nn_max    = (p->nn_max + 31) & ~31; // 256-byte aligned stencil planes
+  p->st_stride = (size_t)9 * s * s * p->nn_max;
+  p->v_stride  = (size_t)p->L_max * p->m_max * p->m_max;
+  p->x_stride  = (size_t)p->L_max * p->m_max * p->nc_max;
+  const size_t per_patch = (p->st_stride + p->v_stride + p->x_stride) * sizeof(double);
+  size_t       budget_mb = 24 * 1024;
+  if (const char *env = std::getenv("SLOD_WORKSPACE_MB"))
+    budget_mb = (size_t)std::max(64L, std::atol(env));
+  p->chunk = std::max<size_t>(1, std::min<size_t>(n, budget_mb * 1024 * 1024 / per_patch));
+  bool ok  = true;
+  ok       = ok && hipMalloc((void **)&p->d_desc, n * sizeof(SlodPatchDesc)) == hipSuccess;
+  ok       = ok && hipMalloc((void **)&p->ws_st, p->chunk * p->st_stride * sizeof(double)) == hipSuccess;
+  ok       = ok && hipMalloc((void **)&p->ws_v, p->chunk * p->v_stride * sizeof(double)) == hipSuccess;
+  ok       = ok && hipMalloc((void **)&p->ws_x, p->chunk * p->x_stride * sizeof(double)) == hipSuccess;
+  ok       = ok && hipMalloc((void **)&p->d_status, sizeof(int32_t)) == hipSuccess;
+  ok = ok && hipMemcpy(p->d_desc, p->desc.data(), n * sizeof(SlodPatchDesc), hipMemcpyHostToDevice) ==
+               hipSuccess;
+  ok = ok && hipMemset(p->d_status, 0, sizeof(int32_t)) == hipSuccess;
+  const size_t n_chunks = (n + p->chunk - 1) / p->chunk;
+  p->ev.resize(4 * n_chunks);
+  for (auto &ev : p->ev)
+    ok = ok && hipEventCreate(&ev) == hipSuccess;
+  if (!ok)
+    {
+      const hipError_t le = hipGetLastError();
+      slod_plan_destroy(p);
+      return hip_fail(h, le, "slod_plan_create: device allocation");
+    }
+  *out = p;
+  return SLOD_OK;
+}
+
+void slod_plan_destroy(slod_plan *p)
+{
+  if (!p)
+    return;
+  for (auto &ev : p->ev)
+    if (ev)
+      (void)hipEventDestroy(ev);
+  if (p->d_desc)
+    (void)hipFree(p->d_desc);
+  if (p->ws_st)
+    (void)hipFree(p->ws_st);
+  if (p->ws_v)
+    (void)hipFree(p->ws_v);
+  if (p->ws_x)
+    (void)hipFree(p->ws_x);
+  if (p->d_status)
+    (void)hipFree(p->d_status);
+  delete p;
+}
+
+size_t slod_plan_stride(const slod_plan *p) { return p ? p->stride : 0; }
+size_t slod_plan_output_size(const slod_plan *p) { return p ? p->out_size : 0; }
+
+int slod_plan_execute(slod_plan *p, double *d_basis, double *d_premult, void *hip_stream)
+{
+  if (!p)
+    return SLOD_ERR_ARGUMENT;
+  slod_handle *h = p->h;
+  if (p->n == 0)
+    return SLOD_OK;
+  if (!d_basis || !d_premult)
+    return fail(h, SLOD_ERR_ARGUMENT, "slod_plan_execute: null output pointer");
+  for (size_t k = 0; k < p->n; ++k)
+    for (int f = 0; f < h->cfg.spacedim; ++f)
+      if (!h->coef_set[(size_t)p->desc[k].prob * 2 + f])
+        return fail(h, SLOD_ERR_STATE, "slod_plan_execute: coefficient field not set");
+  (void)hipSetDevice(h->cfg.device);
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->stream;
+  const int   s  = h->cfg.spacedim;
+  hipError_t  e  = hipMemsetAsync(p->d_status, 0, sizeof(int32_t), st);
+  size_t      ci = 0;
+  for (size_t first = 0; first < p->n && e == hipSuccess; first += p->chunk, ++ci)
+    {
+      const int            cnt = (int)std::min(p->chunk, p->n - first);
+      const SlodKernelArgs a   = make_args(p, first, d_basis, d_premult);
+      hipEvent_t          *ev  = &p->ev[4 * ci];
+      e = hipEventRecord(ev[0], st);
+      if (e == hipSuccess)
+        e = slod_launch_assemble(s, a, cnt, st);
+      if (e == hipSuccess)
+        e = hipEventRecord(ev[1], st);
+      if (e == hipSuccess)
+        e = slod_launch_solve(s, a, cnt, st);
+      if (e == hipSuccess)
+        e = hipEventRecord(ev[2], st);
+      if (e == hipSuccess)
+        e = slod_launch_select(s, a, cnt, p->nb_max, p->nf_max, st);
+      if (e == hipSuccess)
+        e = hipEventRecord(ev[3], st);
+    }
+  if (e != hipSuccess)
+    return hip_fail(h, e, "slod_plan_execute");
+  p->ran = true;
+  return SLOD_OK;
+}
+
+int slod_plan_kernel_ms(slod_plan *p, float ms[3])
+{
+  if (!p || !ms)
+    return SLOD_ERR_ARGUMENT;
+  ms[0] = ms[1] = ms[2] = 0.f;
+  if (!p->ran)
+    return fail(p->h, SLOD_ERR_STATE, "slod_plan_kernel_ms: plan has not been executed");
+  for (size_t c = 0; c < p->ev.size() / 4; ++c)
+    {
+      hipError_t e = hipEventSynchronize(p->ev[4 * c + 3]);
+      for (int k = 0; k < 3 && e == hipSuccess; ++k)
+        {
+          float t = 0.f;
+          e       = hipEventElapsedTime(&t, p->ev[4 * c + k], p->ev[4 * c + k + 1]);
+          ms[k] += t;
+        }
+      if (e != hipSuccess)
+        return hip_fail(p->h, e, "slod_plan_kernel_ms");
+    }
+  return SLOD_OK;
+}
+
+int slod_plan_status(slod_plan *p)
+{
+  if (!p)
+    return SLOD_ERR_ARGUMENT;
+  if (!p->ran || p->n == 0)
+    return SLOD_OK;
+  int32_t    st = 0;
+  hipError_t e  = hipEventSynchronize(p->ev[p->ev.size() - 1]);
+  if (e == hipSuccess)
+    e = hipMemcpy(&st, p->d_status, sizeof(st), hipMemcpyDeviceToHost);
+  if (e != hipSuccess)
+    return hip_fail(p->h, e, "slod_plan_status");
+  if (st)
+    return fail(p->h, SLOD_ERR_NUMERIC, "non-positive pivot in a patch solve (status bits " +
+                                          std::to_string(st) + ")");
+  return SLOD_OK;
+}
+
+int slod_compute_basis(slod_handle *h, const uint32_t *gids, size_t n, double *basis, double *premult,
+                       const uint64_t *offsets)
+{
+  if (!h || (n && (!gids || !basis || !premult)))
+    return SLOD_ERR_ARGUMENT;
+  slod_plan *p  = nullptr;
+  int        rc = slod_plan_create(h, gids, n, offsets, &p);
+  if (rc)
+    return rc;
+  if (n == 0)
+    {
+      slod_plan_destroy(p);
+      return SLOD_OK;
+    }
+  const size_t bytes = slod_plan_output_size(p) * sizeof(double);
+  double      *d_b = nullptr, *d_p = nullptr;
+  hipError_t   e = hipMalloc((void **)&d_b, bytes);
+  if (e == hipSuccess)
+    e = hipMalloc((void **)&d_p, bytes);
+  // gaps between ragged patches stay defined
+  if (e == hipSuccess)
+    e = hipMemsetAsync(d_b, 0, bytes, h->stream);
+  if (e == hipSuccess)
+    e = hipMemsetAsync(d_p, 0, bytes, h->stream);
+  if (e != hipSuccess)
+    rc = hip_fail(h, e, "slod_compute_basis: output allocation");
+  if (!rc)
+    rc = slod_plan_execute(p, d_b, d_p, nullptr);
+  if (!rc)
+    rc = slod_plan_status(p);
+  if (!rc)
+    {
+      // copy back only what the plan wrote (caller gaps untouched)
+      const int s = h->cfg.spacedim;
+      for (size_t k = 0; k < n && e == hipSuccess; ++k)
+        {
+          const SlodPatchDesc &d   = p->desc[k];
+          const size_t         len = (size_t)s * s * (d.nx + 1) * (d.ny + 1) * sizeof(double);
+          e = hipMemcpyAsync(basis + d.out_off, d_b + d.out_off, len, hipMemcpyDeviceToHost, h->stream);
+          if (e == hipSuccess)
+            e = hipMemcpyAsync(premult + d.out_off, d_p + d.out_off, len, hipMemcpyDeviceToHost,
+                               h->stream);
+        }
+      if (e == hipSuccess)
+        e = hipStreamSynchronize(h->stream);
+      if (e != hipSuccess)
+        rc = hip_fail(h, e, "slod_compute_basis: copy back");
+    }
+  if (d_b)
+    (void)hipFree(d_b);
+  if (d_p)
+    (void)hipFree(d_p);
+  slod_plan_destroy(p);
+  return rc;
+}
+
+// ---- pieces for parity tests: run the pipeline for ONE patch and read the workspace ----
+static int run_single(slod_handle *h, uint32_t gid, slod_plan **pp, double **db, double **dp)
+{
+  int rc = slod_plan_create(h, &gid, 1, nullptr, pp);
+  if (rc)
+    return rc;
+  const size_t bytes = slod_plan_output_size(*pp) * sizeof(double);
+  hipError_t   e     = hipMalloc((void **)db, bytes);
+  if (e == hipSuccess)
+    e = hipMalloc((void **)dp, bytes);
+  if (e != hipSuccess)
+    return hip_fail(h, e, "slod debug: allocation");
+  rc = slod_plan_execute(*pp, *db, *dp, nullptr);
+  if (!rc)
+    {
+      e = hipStreamSynchronize(h->stream);
+      if (e != hipSuccess)
+        rc = hip_fail(h, e, "slod debug: execute");
+    }
+  return rc;
+}
+
+int slod_assemble_stiffness_for_patch(slod_handle *h, uint32_t gid, double *stencil)
+{
+  if (!h || !stencil)
+    return SLOD_ERR_ARGUMENT;
+  slod_plan *p  = nullptr;
+  double    *db = nullptr, *dp = nullptr;
+  int        rc = run_single(h, gid, &p, &db, &dp);
+  if (!rc)
+    {
+      const SlodPatchDesc &d  = p->desc[0];
+      const int            s  = h->cfg.spacedim, nn = (d.nx + 1) * (d.ny + 1);
+      std::vector<double>  tmp(p->st_stride);
+      hipError_t e = hipMemcpy(tmp.data(), p->ws_st, p->st_stride * sizeof(double), hipMemcpyDeviceToHost);
+      if (e != hipSuccess)
+        rc = hip_fail(h, e, "slod_assemble_stiffness_for_patch");
+      else
+        for (int node = 0; node < nn; ++node)
+          for (int dir = 0; dir < 9; ++dir)
+            for (int a = 0; a < s; ++a)
+              for (int b = 0; b < s; ++b)
+                stencil[(((size_t)node * 9 + dir) * s + a) * s + b] =
+                  tmp[(size_t)((dir * s + a) * s + b) * p->nn_max + node];
+    }
+  if (db)
+    (void)hipFree(db);
+  if (dp)
+    (void)hipFree(dp);
+  slod_plan_destroy(p);
+  return rc;
+}
+
+int slod_patch_solution(slod_handle *h, uint32_t gid, double *X)
+{
+  if (!h || !X)
+    return SLOD_ERR_ARGUMENT;
+  slod_plan *p  = nullptr;
+  double    *db = nullptr, *dp = nullptr;
+  int        rc = run_single(h, gid, &p, &db, &dp);
+  if (!rc)
+    {
+      const SlodPatchDesc &d = p->desc[0];
+      const int            s = h->cfg.spacedim, npx = d.nx + 1, nf = s * npx * (d.ny + 1);
+      const bool           tr = (d.flags & SLOD_F_TRANSPOSED) != 0;
+      std::vector<double>  tmp(p->x_stride);
+      hipError_t e = hipMemcpy(tmp.data(), p->ws_x, p->x_stride * sizeof(double), hipMemcpyDeviceToHost);
+      if (e != hipSuccess)
+        rc = hip_fail(h, e, "slod_patch_solution");
+      else
+        {
+          std::fill(X, X + (size_t)nf * d.n_c, 0.0);
+          const size_t xline = (size_t)p->m_max * p->nc_max;
+          for (int iy = 1; iy < d.ny; ++iy)
+            for (int ix = 1; ix < d.nx; ++ix)
+              for (int c = 0; c < s; ++c)
+                {
+                  const int l = tr ? ix - 1 : iy - 1, pos = tr ? iy - 1 : ix - 1;
+                  const double *row = tmp.data() + (size_t)l * xline + (size_t)(pos * s + c) * p->nc_max;
+                  for (int k = 0; k < d.n_c; ++k)
+                    X[((size_t)(ix + iy * npx) * s + c) * d.n_c + k] = row[k];
+                }
+        }
+    }
+  if (db)
+    (void)hipFree(db);
+  if (dp)
+    (void)hipFree(dp);
+  slod_plan_destroy(p);
+  return rc;
+}
+
+} // extern "C"

@@ -1,0 +1,150 @@
+/*
+ * include/slod.h -- flat C-ABI of libslod_hip.so: the MI355X-native replacement for the
+ * per-patch SLOD basis construction of camillabelponer/dealii-slod.
+ *
+ * The reference has no FFI; its boundary for this path is the C++ member function
+ *     void LOD<dim,spacedim>::compute_basis_function_candidates()
+ *         (reference include/LOD.h:175-176, source/LOD.cc:296-768)
+ * reading  patches[id].cells / sub_tria, par.{n_global_refinements, n_subdivisions,
+ *          oversampling, LOD_stabilization, constant_coefficients} and the problem's
+ *          coefficient Function (include/Diffusion.h:68, include/Elasticity.h:111-113),
+ * writing  patches[id].basis_function / basis_function_premultiplied
+ *          (include/LOD.h:79-80, source/LOD.cc:592,754,764).
+ * Every entry point below names the reference code it replaces.  INTEGRATION.md shows the
+ * deal.II-side binding (the body a maintainer puts into source/LOD.cc).
+ *
+ * Conventions: plain C types only; return 0 on success, a negative slod_status otherwise
+ * (never throws across the ABI; slod_last_error() gives the text -- the reference throws
+ * deal.II exceptions instead, LODtools.h:416-438).  Caller owns every buffer it passes;
+ * the library owns its device workspace.  A handle is thread-compatible (one thread at a
+ * time), like the reference's non-re-entrant patch loop (LOD.cc:302-322).
+ *
+ * Vector layout: per patch, PATCH-LEXICOGRAPHIC node order, component-minor:
+ *     dof = spacedim*(ix + iy*(nx+1)) + comp,  ix in [0,nx], iy in [0,ny], nx = n_sub*mx.
+ * slod_patch_dof_permutation() maps it to the deal.II patch-local numbering that
+ * Patch::basis_function uses (consumer: assemble_global_matrix, LOD.cc:931-962).
+ */
+#ifndef SLOD_H
+#define SLOD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLOD_ABI_VERSION 1
+
+typedef enum
+{
+  SLOD_OK              = 0,
+  SLOD_ERR_ARGUMENT    = -1, /* bad config / null pointer / id out of range        */
+  SLOD_ERR_UNSUPPORTED = -2, /* dim != 2, spacedim not in {1,2}, patch too large    */
+  SLOD_ERR_DEVICE      = -3, /* HIP runtime error (no GPU, launch failure, OOM)     */
+  SLOD_ERR_STATE       = -4, /* coefficient not set, plan/handle mismatch           */
+  SLOD_ERR_NUMERIC     = -5  /* non-positive pivot in a patch solve                 */
+} slod_status;
+
+/* The five scalars of LODParameters the path reads (include/LOD.h:85-157) + device. */
+typedef struct
+{
+  int32_t dim;                   /* must be 2 (reference: source/LOD.cc:1470-1471)            */
+  int32_t spacedim;              /* 1 = DiffusionProblem, 2 = ElasticityProblem               */
+  int32_t n_global_refinements;  /* N = 2^n coarse cells per side, patches in Morton order    */
+  int32_t n_cells_per_side;      /* 0, or N for a non-2^k grid (then row-major patch order)   */
+  int32_t n_subdivisions;        /* FE_Q_iso_Q1(n) (LOD.cc:87-89)                             */
+  int32_t oversampling;          /* LOD.cc:156-178                                            */
+  int32_t lod_stabilization;     /* 1 = SLOD branch (LOD.cc:563-564)                          */
+  int32_t constant_coefficients; /* quirk Q1: re-use first full patch matrix (LOD.cc:354-362) */
+  int32_t projection_quirk;      /* quirk Q2: projection_P1_P0<2,2> row parity (LODtools.h:43-67) */
+  int32_t n_problems;            /* >= 1 independent coefficient realisations (ensemble)      */
+  int32_t device;                /* HIP device ordinal                                        */
+  int32_t reserved;
+} slod_config;
+
+/* What create_patches()/create_mesh_for_patch() (LOD.cc:122-244,770-858) and
+ * fill_dofs_indices_vector() (LODtools.h:334-375) produce for one patch. */
+typedef struct
+{
+  int32_t cx, cy;          /* centre cell                                                   */
+  int32_t x0, y0, mx, my;  /* patch extent in coarse cells                                  */
+  int32_t nx, ny;          /* fine elements per side                                        */
+  int32_t side_domain[4];  /* left,right,bottom,top: 1 = boundary id 0, 0 = id 99           */
+  int32_t n_fine;          /* N_f  = spacedim*(nx+1)*(ny+1)                                 */
+  int32_t n_internal;      /* N_I                                                           */
+  int32_t n_boundary;      /* N_b  (id-99 dofs)                                             */
+  int32_t n_coarse;        /* N_c  = spacedim*mx*my                                         */
+  int32_t is_lod;          /* branch of LOD.cc:563-564 taken for this patch                 */
+} slod_patch_info;
+
+typedef struct slod_handle slod_handle;
+typedef struct slod_plan   slod_plan;
+
+int         slod_abi_version(void);
+/* text of the last error on this handle (handle may be NULL: last slod_create failure). */
+const char *slod_last_error(const slod_handle *h);
+
+/* replaces LOD::LOD + make_grid + make_fe + initialize_patches (LOD.cc:12-31,65-119,1380-1393) */
+int  slod_create(const slod_config *cfg, slod_handle **out);
+void slod_destroy(slod_handle *h);
+
+/* patches per problem = N*N (LOD.cc:237-242) */
+int slod_num_patches(const slod_handle *h);
+/* replaces create_patches + create_mesh_for_patch + fill_dofs_indices_vector for one patch */
+int slod_patch_layout(const slod_handle *h, uint32_t patch_id, slod_patch_info *info);
+/* patch->cells in the reference's order, centre first (LOD.cc:151-178); entries cx + N*cy */
+int slod_patch_cells(const slod_handle *h, uint32_t patch_id, uint32_t *cells, size_t capacity);
+/* perm[dealii_dof] = lexicographic dof, for DoFHandler::distribute_dofs(FESystem(FE_Q_iso_Q1(n),
+ * spacedim)) on the patch sub_tria (LOD.cc:365-366); see DESIGN.md for the numbering rule. */
+int slod_patch_dof_permutation(const slod_handle *h, uint32_t patch_id, uint32_t *perm,
+                               size_t capacity);
+/* Utilities::MPI::create_evenly_distributed_partitioning (LOD.cc:116-118) */
+int slod_partition(uint64_t n_total, uint32_t n_ranks, uint32_t rank, uint64_t *begin,
+                   uint64_t *end);
+
+/* Coefficient field of problem `problem` (replaces Alpha/Lambda/Mu.value_list at the
+ * quadrature points, Diffusion.h:154, Elasticity.h:208-209).  field 0 = alpha or lambda,
+ * 1 = mu.  layout 0: one value per fine element, [NE][NE] row-major (ex fastest);
+ * layout 1: four values per element, [NE][NE][4], q = q0 + 2*q1 of QIterated(QGauss<1>(2),n)
+ * (LOD.cc:91-92).  NE = N*n_subdivisions.  `on_device` != 0: data is a device pointer. */
+int slod_set_coefficient(slod_handle *h, uint32_t problem, int field, const double *data,
+                         int layout, size_t count, int on_device);
+
+/* ---- the hot path ------------------------------------------------------------------ */
+/* A plan fixes the list of (global) patch ids  gid = problem*num_patches + patch_id  and
+ * where each patch's result goes (offsets in doubles into basis/premult; NULL = uniform
+ * stride slod_plan_stride()).  Replaces the loop header LOD.cc:345-352. */
+int    slod_plan_create(slod_handle *h, const uint32_t *gids, size_t n, const uint64_t *offsets,
+                        slod_plan **out);
+void   slod_plan_destroy(slod_plan *p);
+size_t slod_plan_stride(const slod_plan *p);       /* doubles per patch with NULL offsets   */
+size_t slod_plan_output_size(const slod_plan *p);  /* doubles needed in basis (and premult) */
+/* Runs the loop body LOD.cc:353-767 for every patch of the plan on the GPU.  d_basis /
+ * d_premult are DEVICE pointers; per patch: spacedim vectors of n_fine doubles each
+ * (= Patch::basis_function[d], Patch::basis_function_premultiplied[d]).  Asynchronous on
+ * `hip_stream` (a hipStream_t, NULL = the handle's own stream). */
+int slod_plan_execute(slod_plan *p, double *d_basis, double *d_premult, void *hip_stream);
+/* per-kernel device time of the last slod_plan_execute, measured with HIP events on the
+ * stream the kernels ran on; synchronises.  which: 0 assemble, 1 patch solve, 2 selection */
+int slod_plan_kernel_ms(slod_plan *p, float ms[3]);
+/* numerical status of the last execute (0 or SLOD_ERR_NUMERIC); synchronises. */
+int slod_plan_status(slod_plan *p);
+
+/* Host-buffer convenience wrapper: plan + execute + copy back (what the deal.II adapter
+ * calls).  basis/premult are HOST pointers. */
+int slod_compute_basis(slod_handle *h, const uint32_t *gids, size_t n, double *basis,
+                       double *premult, const uint64_t *offsets);
+
+/* ---- pieces exposed for parity tests ----------------------------------------------- */
+/* unconstrained patch stiffness (replaces assemble_stiffness with empty constraints,
+ * LOD.cc:440-444 -> Diffusion.h:111-207 / Elasticity.h:163-299) as a 9-point block stencil:
+ * stencil[node][dir][a][b], dir = (dy+1)*3+(dx+1).  HOST buffer of n_nodes*9*s*s doubles. */
+int slod_assemble_stiffness_for_patch(slod_handle *h, uint32_t gid, double *stencil);
+/* Ainv_PT of Gauss_elimination (LOD.cc:546): HOST buffer [n_fine][n_coarse] row-major. */
+int slod_patch_solution(slod_handle *h, uint32_t gid, double *X);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLOD_H */

@@ -580,6 +580,16 @@ int so_patch_solve(const so_cfg *cfg, const so_patch *p, const double *stencil, 
   return rc;
 }
 
+/* dense un-zeroed P^T, [n_f][n_c] row-major (LOD.cc:471-496, before LOD.cc:512-518) */
+void so_patch_pt(const so_cfg *cfg, int pid, double *PT)
+{
+  so_patch p;
+  so_patch_init(cfg, pid, &p);
+  memset(PT, 0, sizeof(double) * (size_t)p.n_f * p.n_c);
+  pt_dense_ctx ctx = {PT, p.n_c, &p, cfg->spacedim};
+  pt_foreach(cfg, &p, pt_dense_visit, &ctx);
+}
+
 /* ------------------------------------------------------------------------- */
 /* small dense helpers                                                       */
 /* ------------------------------------------------------------------------- */
@@ -654,7 +664,7 @@ static void jacobi_one_sided(int m, int n, double *W, double *V)
                 aqq += wq * wq;
                 apq += wp * wq;
               }
-            if (apq == 0.0 || fabs(apq) <= 1e-17 * sqrt(app * aqq))
+            if (apq == 0.0 || fabs(apq) <= 1e-15 * sqrt(app * aqq))
               continue;
             rotated          = 1;
             const double zeta = (aqq - app) / (2.0 * apq);

@@ -105,6 +105,9 @@ int  so_basis_many(const so_cfg *cfg, const double *const *coef, const int *ids,
 int  so_patch_debug(const so_cfg *cfg, const double *const *coef, int pid,
                     double *M, double *D, double *BD, int *bdofs, double *X);
 
+/* dense un-zeroed P^T [n_f][n_c] (LOD.cc:471-496) */
+void so_patch_pt(const so_cfg *cfg, int pid, double *PT);
+
 /* 0 (default): one-sided Jacobi SVD of BD'; 1: literal Gram matrix G = BD'^T BD' +
  * Jacobi eigen-solver (LOD.cc:660-667 with dgesdd replaced). */
 void so_set_svd_mode(int mode);

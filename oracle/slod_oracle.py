@@ -64,6 +64,7 @@ def lib():
         _lib.so_patch_cells.argtypes = [C.POINTER(Cfg), C.POINTER(Patch), C.POINTER(C.c_int)]
         _lib.so_num_patches.argtypes = [C.POINTER(Cfg)]
         _lib.so_set_svd_mode.argtypes = [C.c_int]
+        _lib.so_patch_pt.argtypes = [C.POINTER(Cfg), C.c_int, dp]
     return _lib
 
 
@@ -206,3 +207,10 @@ def fe_q_iso_q1_cell_matrix(dim, n):
 
 def set_svd_mode(mode):
     lib().so_set_svd_mode(mode)
+
+
+def patch_pt(cfg, pid):
+    p = patch_info(cfg, pid)
+    PT = np.zeros((p.n_f, p.n_c))
+    lib().so_patch_pt(C.byref(cfg), pid, _dp(PT))
+    return PT

@@ -1,0 +1,107 @@
+"""GPU parity tests: HIP path (through the C-ABI) vs the CPU oracle, same seeded inputs.
+
+Tolerances (written here as the task demands):
+  phi : unit-l2-norm vectors, absolute 1e-10 (BASELINE.json north_star)
+  psi : psi = A_semi phi, so a 1e-10 perturbation of phi moves psi by up to ||A||_inf*1e-10;
+        tolerance 1e-10 * ||A||_inf (max stencil row sum of the patch).
+"""
+import numpy as np
+import pytest
+
+from conftest import make_fields
+
+pytestmark = pytest.mark.gpu
+
+TOL_PHI = 1e-10
+
+
+def _mk(so, **kw):
+    import slod_amd
+    cfg = so.make_cfg(**kw)
+    g = slod_amd.Slod(nref=kw.get("nref", 0), n_sub=kw["n_sub"], oversampling=kw["oversampling"],
+                      spacedim=kw.get("spacedim", 1), stabilize=kw.get("stabilize", 1),
+                      reuse_full=kw.get("reuse_full", 0), proj_quirk=kw.get("proj_quirk", 0),
+                      n_cells=kw.get("n_cells", 0))
+    return cfg, g
+
+
+def _upload(g, fields):
+    for f, a in enumerate(fields):
+        g.set_coefficient(f, a)
+
+
+def _check_patch(so, cfg, fields, pid, basis, premult, off, label=""):
+    p = so.patch_info(cfg, pid)
+    s = cfg.spacedim
+    phi, psi, _ = so.patch_basis(cfg, fields, pid)
+    st = so.assemble_patch(cfg, fields, pid)
+    a_inf = np.abs(st).sum(axis=(1, 3)).max()
+    n = s * p.n_f
+    gphi = basis[off:off + n].reshape(s, p.n_f)
+    gpsi = premult[off:off + n].reshape(s, p.n_f)
+    ephi = np.abs(gphi - phi).max()
+    epsi = np.abs(gpsi - psi).max()
+    assert np.isfinite(gphi).all() and np.isfinite(gpsi).all(), label
+    assert ephi <= TOL_PHI, "%s patch %d: |dphi| = %.3e" % (label, pid, ephi)
+    assert epsi <= TOL_PHI * a_inf, "%s patch %d: |dpsi| = %.3e (tol %.3e)" % (label, pid, epsi, TOL_PHI * a_inf)
+    return ephi, epsi / a_inf
+
+
+def test_stencil_matches_oracle(so):
+    cfg, g = _mk(so, nref=3, n_sub=4, oversampling=1)
+    fields = make_fields(so, cfg, "D100")
+    _upload(g, fields)
+    for pid in (0, 9, 27, 63):
+        st = g.assemble_stiffness_for_patch(pid)
+        ref = so.assemble_patch(cfg, fields, pid)
+        assert np.abs(st - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+def test_patch_solution_matches_oracle(so):
+    cfg, g = _mk(so, nref=3, n_sub=4, oversampling=1)
+    fields = make_fields(so, cfg, "D100")
+    _upload(g, fields)
+    for pid in (0, 9, 27, 63):
+        X = g.patch_solution(pid)
+        ref = so.patch_debug(cfg, fields, pid)["X"]
+        assert np.abs(X - ref).max() <= 1e-11 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("stabilize", [0, 1])
+@pytest.mark.parametrize("dist", ["const", "D100"])
+def test_small_config_all_patches(so, stabilize, dist):
+    """(test) Poisson_LOD_Example geometry: H=1/4, n=2, l=1 -- all 16 patches."""
+    cfg, g = _mk(so, nref=2, n_sub=2, oversampling=1, stabilize=stabilize)
+    fields = make_fields(so, cfg, dist)
+    _upload(g, fields)
+    ids = np.arange(g.num_patches)
+    basis, premult, offs = g.compute_basis(ids)
+    for k, pid in enumerate(ids):
+        _check_patch(so, cfg, fields, int(pid), basis, premult, int(offs[k]), "small")
+
+
+@pytest.mark.parametrize("stabilize", [0, 1])
+def test_c1_all_patches(so, stabilize):
+    """BASELINE config C1: H=1/8, n=4, l=1, 64 patches."""
+    cfg, g = _mk(so, nref=3, n_sub=4, oversampling=1, stabilize=stabilize)
+    fields = make_fields(so, cfg, "D100")
+    _upload(g, fields)
+    ids = np.arange(g.num_patches)
+    basis, premult, offs = g.compute_basis(ids)
+    for k, pid in enumerate(ids):
+        _check_patch(so, cfg, fields, int(pid), basis, premult, int(offs[k]), "C1")
+
+
+@pytest.mark.parametrize("dist", ["D100", "D1e4"])
+def test_c2_all_patches(so, dist):
+    """BASELINE config C2 (north star): H=1/32, n=8, l=2, SLOD, all 1024 patches."""
+    cfg, g = _mk(so, nref=5, n_sub=8, oversampling=2, stabilize=1)
+    fields = make_fields(so, cfg, dist)
+    _upload(g, fields)
+    ids = np.arange(g.num_patches)
+    basis, premult, offs = g.compute_basis(ids)
+    worst = (0.0, 0.0)
+    for k, pid in enumerate(ids):
+        e = _check_patch(so, cfg, fields, int(pid), basis, premult, int(offs[k]), "C2/" + dist)
+        worst = (max(worst[0], e[0]), max(worst[1], e[1]))
+    print("C2 %s worst |dphi| %.3e, |dpsi|/||A|| %.3e" % (dist, worst[0], worst[1]))
