@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py -- SLOD basis-construction throughput on MI355X (one JSON line on rank 0).
+
+Metric (BASELINE.json / SURVEY.md section 8d): SLOD patches/s (basis built) for the
+north-star configuration C2 = 2-D Poisson, H=1/32, n_sub=8, oversampling 2, SLOD,
+random log-uniform coefficient of contrast 1e4 (D1e4, splitmix64 seed 20250614), fp64.
+
+A "step" = one pass of the hot path over the rank's whole patch list: stencil assembly,
+constrained 25-RHS patch solve, boundary trace + SVD selection, normalisation and
+premultiplication for every patch (reference source/LOD.cc:345-767), inputs (the
+coefficient field) and outputs (phi, psi) resident in HBM.
+
+N GPUs (weak scaling): the workload is an ensemble of N independent coefficient
+realisations of C2 (N*1024 patches); the global patch list is split in contiguous blocks
+exactly like Utilities::MPI::create_evenly_distributed_partitioning (LOD.cc:116-118), one
+block per rank, no data-path collective inside the timed basis build.  After the timed
+region every rank's (phi,psi) slab is all-gathered over RCCL (north_star's exchange step);
+that time is reported separately as `allgather_ms` (SURVEY 8d excludes it from the metric).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "dealii-slod_amd"))
+
+SEED = 20250614
+C2 = dict(nref=5, n_sub=8, oversampling=2, spacedim=1, stabilize=1)
+PEAK_FP64_TFLOPS = 78.6   # MI355X dense fp64 (vector = matrix): half the 157.3 TF fp32 vector peak
+PEAK_HBM_GBPS = 8000.0    # /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def canonical_counts(slod, gids):
+    """Algorithmic flops of the patch solve (banded Cholesky in patch-lexicographic order,
+    SURVEY 8d: N_I(b^2+3b) + 4 N_c N_I b) and algorithmic bytes 8*(4*E + 2*s*N_f)."""
+    s, n = slod.spacedim, slod.cfg.n_subdivisions
+    flops = 0.0
+    nbytes = 0.0
+    cache = {}
+    for g in gids:
+        pid = int(g) % slod.num_patches
+        info = slod.patch_layout(pid)
+        key = (info.mx, info.my)
+        if key not in cache:
+            b = s * (n * min(info.mx, info.my) - 1) + s - 1
+            ni, nc = info.n_internal, info.n_coarse
+            e = info.nx * info.ny
+            cache[key] = (ni * (b * b + 3 * b) + 4.0 * nc * ni * b, 8.0 * (4 * e * s + 2 * s * info.n_fine))
+        flops += cache[key][0]
+        nbytes += cache[key][1]
+    return flops, nbytes
+
+
+def cpu_baseline(cfg_kw, fields, n_full):
+    """The C oracle (kind 'port': our CPU restatement, the reference cannot be built here)
+    timed on this box's host cores on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import slod_oracle as so
+    cfg = so.make_cfg(**cfg_kw)
+    s = cfg.spacedim
+    ids = np.arange(n_full, dtype=np.int32)
+    sizes = np.array([s * so.patch_info(cfg, int(p)).n_f for p in ids], dtype=np.int64)
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    total = int(sizes.sum())
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    # 1 thread: the reference's execution model per rank (MPI_InitFinalize(...,1)); 128 patches
+    sub = ids[::8]
+    t0 = time.perf_counter()
+    so.basis_many(cfg, fields, sub, offs[::8], total, nthreads=1)
+    t1 = time.perf_counter() - t0
+    # all cores, OpenMP over patches: the reference's scale-out model (locally_owned_patches)
+    reps = 0
+    t0 = time.perf_counter()
+    while True:
+        so.basis_many(cfg, fields, ids, offs, total, nthreads=cores)
+        reps += 1
+        tall = time.perf_counter() - t0
+        if tall > 4.0 or reps >= 20:
+            break
+    return {"value": reps * len(ids) / tall, "unit": "patches/s", "cores": cores, "kind": "port",
+            "sample": "all %d patches of C2 x %d passes, OpenMP over patches (%.1f s wall); "
+                      "1 thread on every 8th patch: %.1f patches/s" % (len(ids), reps, tall, len(sub) / t1),
+            "value_1thread": len(sub) / t1}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist", default="D1e4", choices=["D100", "D1e4"])
+    args = ap.parse_args()
+
+    import torch
+    import slod_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                             "--master-addr 127.0.0.1 bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # ---- workload: ensemble of `world` realisations of C2, this rank's contiguous block
+    slod = slod_amd.Slod(n_problems=world, device=local_rank, **C2)
+    NP = slod.num_patches
+    total = NP * world
+    begin, end = slod_amd.partition(total, world, rank)
+    gids = np.arange(begin, end, dtype=np.uint32)
+    from slod_amd.synthetic import fill_coefficient
+    lo, hi = (1.0, 100.0) if args.dist == "D100" else (1.0, 1.0e4)
+    probs = sorted(set(int(g) // NP for g in gids))
+    fields = {}
+    for pb in probs:
+        fields[pb] = fill_coefficient(SEED + 1000 * pb, args.dist, slod.NE)
+        t = torch.from_numpy(fields[pb]).to(dev)                  # resident in HBM before timing
+        slod.set_coefficient_device(0, t.data_ptr(), t.numel(), problem=pb)
+    plan = slod.plan(gids)                                        # uniform stride -> all-gather slabs
+    n_local = len(gids)
+    n_slab = (total + world - 1) // world                         # padded slab (ragged tail)
+    basis = torch.zeros(n_slab * plan.stride, dtype=torch.float64, device=dev)
+    premult = torch.zeros(n_slab * plan.stride, dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        plan.execute(basis.data_ptr(), premult.data_ptr(), stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    plan.status()
+
+    plan.profile(args.steps)          # HIP events around every launch of the timed region
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    plan.status()
+    # mean per-kernel device time over the timed region (events on the launch stream)
+    ks = np.array(plan.kernel_ms())
+
+    # the exchange step (outside the metric): RCCL all-gather of the (phi,psi) slabs
+    allgather_ms = None
+    if world > 1:
+        gb = torch.empty(world * basis.numel(), dtype=torch.float64, device=dev)
+        gp = torch.empty(world * premult.numel(), dtype=torch.float64, device=dev)
+        for _ in range(2):
+            dist.all_gather_into_tensor(gb, basis)
+            dist.all_gather_into_tensor(gp, premult)
+        barrier()
+        ta = time.perf_counter()
+        dist.all_gather_into_tensor(gb, basis)
+        dist.all_gather_into_tensor(gp, premult)
+        barrier()
+        allgather_ms = (time.perf_counter() - ta) * 1e3
+        # every rank's block must land where a single-GPU run would put it
+        mine = gb[rank * basis.numel():(rank + 1) * basis.numel()]
+        assert torch.equal(mine, basis)
+        tmax = torch.tensor([elapsed, allgather_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed, allgather_ms = float(tmax[0]), float(tmax[1])
+
+    if rank == 0:
+        flops, nbytes = canonical_counts(slod, gids)
+        ms_step = elapsed / args.steps * 1e3
+        solve_s = ks[1] * 1e-3
+        achieved_tf = flops / solve_s / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("k_solve_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "SLOD patches/sec (basis built), 2D Poisson H=1/32 n_sub=8 oversampling 2",
+            "value": total * args.steps / elapsed,
+            "unit": "patches/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C2: 2D Poisson SLOD, H=1/32, n_sub=8, oversampling=2, "
+                                   "%s coefficient (contrast %g), %d patches per GPU "
+                                   "(ensemble of %d realisations, contiguous patch blocks)"
+                                   % (args.dist, hi / lo, n_local, world),
+                       "patches_per_gpu": n_local, "parallelism": "patch-sharded x%d" % world},
+            "roofline": {"bound": "mfma", "kernel": "k_solve<3,1>",
+                         "achieved": achieved_tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved_tf / PEAK_FP64_TFLOPS, "traffic": traffic,
+                         "algorithmic_flops_per_launch": flops,
+                         "kernel_ms": {"assemble": ks[0], "solve": ks[1], "select": ks[2]},
+                         "hbm_algorithmic_bytes_per_step": nbytes,
+                         "hbm_achieved_GBps": nbytes / (ms_step * 1e-3) / 1e9,
+                         "hbm_frac": nbytes / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBPS},
+            "allgather_ms": allgather_ms,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(C2, [fields[probs[0]]], NP)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

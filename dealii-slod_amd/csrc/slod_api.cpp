@@ -48,7 +48,10 @@ struct slod_plan
   double                    *ws_st = nullptr, *ws_v = nullptr, *ws_x = nullptr;
   size_t                     st_stride = 0, v_stride = 0, x_stride = 0;
   int32_t                   *d_status = nullptr;
-  std::vector<hipEvent_t>    ev; // 4 per chunk
+  std::vector<hipEvent_t>    ev; // [depth][n_chunks][4]
+  size_t                     n_chunks = 0;
+  int                        depth = 1; // event slots (slod_plan_profile)
+  size_t                     n_exec = 0;
   bool                       ran = false;
 };
 
@@ -522,8 +525,8 @@ int slod_plan_create(slod_handle *h, const uint32_t *gids, size_t n, const uint6
   ok = ok && hipMemcpy(p->d_desc, p->desc.data(), n * sizeof(SlodPatchDesc), hipMemcpyHostToDevice) ==
                hipSuccess;
   ok = ok && hipMemset(p->d_status, 0, sizeof(int32_t)) == hipSuccess;
-  const size_t n_chunks = (n + p->chunk - 1) / p->chunk;
-  p->ev.resize(4 * n_chunks);
+  p->n_chunks = (n + p->chunk - 1) / p->chunk;
+  p->ev.assign(4 * p->n_chunks, nullptr);
   for (auto &ev : p->ev)
     ok = ok && hipEventCreate(&ev) == hipSuccess;
   if (!ok)
@@ -581,7 +584,7 @@ int slod_plan_execute(slod_plan *p, double *d_basis, double *d_premult, void *hi
     {
       const int            cnt = (int)std::min(p->chunk, p->n - first);
       const SlodKernelArgs a   = make_args(p, first, d_basis, d_premult);
-      hipEvent_t          *ev  = &p->ev[4 * ci];
+      hipEvent_t          *ev  = &p->ev[4 * ((p->n_exec % (size_t)p->depth) * p->n_chunks + ci)];
       e = hipEventRecord(ev[0], st);
       if (e == hipSuccess)
         e = slod_launch_assemble(s, a, cnt, st);
@@ -599,6 +602,28 @@ int slod_plan_execute(slod_plan *p, double *d_basis, double *d_premult, void *hi
   if (e != hipSuccess)
     return hip_fail(h, e, "slod_plan_execute");
   p->ran = true;
+  ++p->n_exec;
+  return SLOD_OK;
+}
+
+int slod_plan_profile(slod_plan *p, int depth)
+{
+  if (!p || depth < 1)
+    return SLOD_ERR_ARGUMENT;
+  if (p->n == 0)
+    return SLOD_OK;
+  (void)hipSetDevice(p->h->cfg.device);
+  (void)hipDeviceSynchronize();
+  for (auto &ev : p->ev)
+    if (ev)
+      (void)hipEventDestroy(ev);
+  p->ev.assign((size_t)depth * p->n_chunks * 4, nullptr);
+  for (auto &ev : p->ev)
+    if (hipEventCreate(&ev) != hipSuccess)
+      return hip_fail(p->h, hipGetLastError(), "slod_plan_profile: hipEventCreate");
+  p->depth  = depth;
+  p->n_exec = 0;
+  p->ran    = false;
   return SLOD_OK;
 }
 
@@ -609,18 +634,24 @@ int slod_plan_kernel_ms(slod_plan *p, float ms[3])
   ms[0] = ms[1] = ms[2] = 0.f;
   if (!p->ran)
     return fail(p->h, SLOD_ERR_STATE, "slod_plan_kernel_ms: plan has not been executed");
-  for (size_t c = 0; c < p->ev.size() / 4; ++c)
-    {
-      hipError_t e = hipEventSynchronize(p->ev[4 * c + 3]);
-      for (int k = 0; k < 3 && e == hipSuccess; ++k)
-        {
-          float t = 0.f;
-          e       = hipEventElapsedTime(&t, p->ev[4 * c + k], p->ev[4 * c + k + 1]);
-          ms[k] += t;
-        }
-      if (e != hipSuccess)
-        return hip_fail(p->h, e, "slod_plan_kernel_ms");
-    }
+  const size_t slots = std::min<size_t>(p->n_exec, (size_t)p->depth);
+  double       acc[3] = {0, 0, 0};
+  for (size_t sl = 0; sl < slots; ++sl)
+    for (size_t c = 0; c < p->n_chunks; ++c)
+      {
+        hipEvent_t *ev = &p->ev[4 * (sl * p->n_chunks + c)];
+        hipError_t  e  = hipEventSynchronize(ev[3]);
+        for (int k = 0; k < 3 && e == hipSuccess; ++k)
+          {
+            float t = 0.f;
+            e       = hipEventElapsedTime(&t, ev[k], ev[k + 1]);
+            acc[k] += t;
+          }
+        if (e != hipSuccess)
+          return hip_fail(p->h, e, "slod_plan_kernel_ms");
+      }
+  for (int k = 0; k < 3; ++k)
+    ms[k] = (float)(acc[k] / (double)slots);
   return SLOD_OK;
 }
 
@@ -631,7 +662,7 @@ int slod_plan_status(slod_plan *p)
   if (!p->ran || p->n == 0)
     return SLOD_OK;
   int32_t    st = 0;
-  hipError_t e  = hipEventSynchronize(p->ev[p->ev.size() - 1]);
+  hipError_t e  = hipDeviceSynchronize();
   if (e == hipSuccess)
     e = hipMemcpy(&st, p->d_status, sizeof(st), hipMemcpyDeviceToHost);
   if (e != hipSuccess)

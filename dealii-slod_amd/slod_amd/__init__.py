@@ -45,6 +45,15 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise OSError("libslod_hip.so not built: run `make -C dealii-slod_amd` "
                       "(or __graft_entry__.build()); there is no CPU fallback")
+    # One HIP runtime per process: PyTorch ships its own libamdhip64 (soname libamdhip64.so.7,
+    # the same as /opt/rocm's).  If torch is imported AFTER this library, a second runtime
+    # gets loaded and whichever initialises second sees no device.  Importing torch first
+    # makes libslod_hip bind to torch's copy (torch is only plumbing here: device memory,
+    # streams, torch.distributed).  Non-Python users link /opt/rocm's runtime as usual.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, dp, u32p, u64p = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
     lib.slod_abi_version.restype = C.c_int
@@ -68,6 +77,7 @@ def load():
     lib.slod_plan_output_size.restype = C.c_size_t
     lib.slod_plan_execute.argtypes = [vp, vp, vp, vp]
     lib.slod_plan_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.slod_plan_profile.argtypes = [vp, C.c_int]
     lib.slod_plan_status.argtypes = [vp]
     lib.slod_compute_basis.argtypes = [vp, u32p, C.c_size_t, dp, dp, u64p]
     lib.slod_assemble_stiffness_for_patch.argtypes = [vp, C.c_uint32, dp]
@@ -114,6 +124,9 @@ class Plan:
     def execute(self, d_basis_ptr, d_premult_ptr, stream_ptr=None):
         """Asynchronous launch; arguments are raw device pointers (ints)."""
         self.slod._check(self.lib.slod_plan_execute(self.p, d_basis_ptr, d_premult_ptr, stream_ptr))
+
+    def profile(self, depth):
+        self.slod._check(self.lib.slod_plan_profile(self.p, depth))
 
     def kernel_ms(self):
         ms = (C.c_float * 3)()

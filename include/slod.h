@@ -125,8 +125,11 @@ size_t slod_plan_output_size(const slod_plan *p);  /* doubles needed in basis (a
  * (= Patch::basis_function[d], Patch::basis_function_premultiplied[d]).  Asynchronous on
  * `hip_stream` (a hipStream_t, NULL = the handle's own stream). */
 int slod_plan_execute(slod_plan *p, double *d_basis, double *d_premult, void *hip_stream);
-/* per-kernel device time of the last slod_plan_execute, measured with HIP events on the
- * stream the kernels ran on; synchronises.  which: 0 assemble, 1 patch solve, 2 selection */
+/* Keep HIP-event records of the next `depth` executes (default 1 = the last one only);
+ * resets the record.  The events sit on the stream the kernels are launched on. */
+int slod_plan_profile(slod_plan *p, int depth);
+/* mean per-kernel device time over the recorded executes (HIP events around every launch);
+ * synchronises.  ms[0] assemble, ms[1] patch solve, ms[2] selection */
 int slod_plan_kernel_ms(slod_plan *p, float ms[3]);
 /* numerical status of the last execute (0 or SLOD_ERR_NUMERIC); synchronises. */
 int slod_plan_status(slod_plan *p);
