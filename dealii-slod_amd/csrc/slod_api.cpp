@@ -43,6 +43,7 @@ struct slod_plan
   std::vector<SlodPatchDesc> desc;
   SlodPatchDesc             *d_desc = nullptr;
   int                        m_max = 0, L_max = 0, nc_max = 0, nb_max = 0, nn_max = 0, nf_max = 0;
+  int                        nb_buf = 0; // rows of k_select's boundary-trace buffer
   size_t                     stride = 0, out_size = 0;
   size_t                     chunk = 0;
   double                    *ws_st = nullptr, *ws_v = nullptr, *ws_x = nullptr;
@@ -226,6 +227,8 @@ namespace
     a.NE          = h->NE;
     a.n_sub       = h->cfg.n_subdivisions;
     a.quirk       = h->cfg.projection_quirk;
+    if (const char *dg = std::getenv("SLOD_DIAG"))
+      a.diag = std::atoi(dg); // timing experiments only: results are wrong when non-zero
     const double H = 1.0 / (double)h->N, hh = H / (double)h->cfg.n_subdivisions;
     a.scale     = hh * hh / 4.0; // LOD.cc:341
     a.invH2     = 1.0 / (H * H); // LOD.cc:551
@@ -465,6 +468,7 @@ int slod_plan_create(slod_handle *h, const uint32_t *gids, size_t n, const uint6
   const int s = h->cfg.spacedim, n_sub = h->cfg.n_subdivisions, full = 2 * h->cfg.oversampling + 1;
   // uniform stride = the full patch's s vectors of n_fine (what an all-gather slab uses)
   p->stride = (size_t)s * s * (size_t)(n_sub * full + 1) * (size_t)(n_sub * full + 1);
+  int nb_min_slod = 1 << 30;
   for (size_t k = 0; k < n; ++k)
     {
       if (gids[k] >= total)
@@ -479,6 +483,7 @@ int slod_plan_create(slod_handle *h, const uint32_t *gids, size_t n, const uint6
       p->L_max        = std::max(p->L_max, (int)d.L);
       p->nc_max       = std::max(p->nc_max, (int)d.n_c);
       p->nb_max       = std::max(p->nb_max, (d.flags & SLOD_F_LOD) ? 0 : (int)d.n_b);
+      nb_min_slod     = (d.flags & SLOD_F_LOD) ? nb_min_slod : std::min(nb_min_slod, (int)d.n_b);
       p->nn_max       = std::max(p->nn_max, nn);
       p->nf_max       = std::max(p->nf_max, s * nn);
       p->out_size     = std::max(p->out_size, (size_t)d.out_off + (size_t)s * s * nn);
@@ -500,9 +505,13 @@ int slod_plan_create(slod_handle *h, const uint32_t *gids, size_t n, const uint6
       return fail(h, SLOD_ERR_UNSUPPORTED, "slod_plan_create: more than 64 coarse dofs per patch");
     }
   hipError_t e = hipSuccess;
+  (void)nb_min_slod;
+  // k_select reduces the boundary-trace matrix by QR in row chunks (TSQR): the LDS buffer
+  // holds nb_buf rows, at least nc_max + 16 so every chunk brings new rows
+  p->nb_buf = std::min(p->nb_max, std::max(96, p->nc_max + 16));
   const size_t lds_max = 160 * 1024;
   if (slod_solve_lds_bytes(s, p->m_max, p->nc_max) > lds_max ||
-      slod_select_lds_bytes(s, p->nb_max, p->nc_max, p->nf_max) > lds_max)
+      slod_select_lds_bytes(s, p->nb_buf, p->nc_max, p->nf_max) > lds_max)
     {
       delete p;
       return fail(h, SLOD_ERR_UNSUPPORTED, "slod_plan_create: patch does not fit the 160 KB LDS");
@@ -595,7 +604,7 @@ int slod_plan_execute(slod_plan *p, double *d_basis, double *d_premult, void *hi
       if (e == hipSuccess)
         e = hipEventRecord(ev[2], st);
       if (e == hipSuccess)
-        e = slod_launch_select(s, a, cnt, p->nb_max, p->nf_max, st);
+        e = slod_launch_select(s, a, cnt, p->nb_buf, p->nf_max, st);
       if (e == hipSuccess)
         e = hipEventRecord(ev[3], st);
     }

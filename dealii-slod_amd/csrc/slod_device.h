@@ -38,6 +38,7 @@ struct SlodKernelArgs
   int32_t              NE;          // fine elements per side of the global grid
   int32_t              n_sub;
   int32_t              quirk;       // projection quirk Q2
+  int32_t              diag;        // timing diagnostics only (env SLOD_DIAG): phase skip mask
   double               scale;       // h^2/4
   double               invH2;       // 1/H^dim
   // workspace (one slot per patch of the launch)

@@ -178,34 +178,94 @@ namespace
   //     Z_l = V_l (F_l - B_{l-1}^T Z_{l-1}),
   // backward substitution  X_l = Z_l - V_l B_l X_{l+1}.
   // V_l (m x m) is computed IN REGISTERS: a 16x16 thread grid holds an R x R strided tile
-  // each (entry (ty+16a, tx+16b)); the symmetric Gauss-Jordan sweep needs only pivot row k,
-  // which its 16 owner threads publish to a double-buffered LDS row => one barrier per
-  // pivot.  V_l and Z_l go to the per-patch global workspace for the backward pass (they
-  // do not fit the 160 KB LDS: 39 lines x 12 KB at the north-star size).
+  // each (entry (ty+16a, tx+16b)).  The symmetric Gauss-Jordan sweep needs only pivot row
+  // k: the wave that owns it computes 1/pivot once and publishes the row r and the scaled
+  // row s = r/pivot to a double-buffered LDS line, so a pivot step costs every thread
+  // 2R LDS reads + R*R FMAs and ONE barrier.  V_l and Z_l go to the per-patch global
+  // workspace for the backward pass (39 lines x 12 KB do not fit the 160 KB LDS).
+  // The two GEMMs per line use R x 2 register tiles fed by 128-bit LDS reads.
+  constexpr int kColGroup = 32; // right-hand sides per GEMM pass (2 per thread column)
+
+  __host__ __device__ constexpr int solve_min_waves(int R) { return R <= 3 ? 4 : (R == 4 ? 2 : 1); }
+
+  // 1/d to ~1 ulp: v_rcp_f64 + two Newton steps.  Only the pivot thread runs it, and it sits
+  // on the latency chain of every Gauss-Jordan step, so the ~30-instruction IEEE division
+  // sequence is avoided.
+  __device__ __forceinline__ double fast_rcp(double d)
+  {
+    double x = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, x, 1.0);
+    x        = fma(x, e, x);
+    e        = fma(-d, x, 1.0);
+    return fma(x, e, x);
+  }
+
+  template <int R>
+  __device__ __forceinline__ void gemm_tile(const double *__restrict__ Vs, int ldv,
+                                            const double *__restrict__ Rb, int ncs, int m_even,
+                                            int ty, int col0, double (&acc)[R][2])
+  {
+#pragma unroll
+    for (int ra = 0; ra < R; ++ra)
+      acc[ra][0] = acc[ra][1] = 0.0;
+    const double *rp = Rb + col0;
+    for (int k = 0; k < m_even; k += 2)
+      {
+        const double2 r0 = *reinterpret_cast<const double2 *>(rp + k * ncs);
+        const double2 r1 = *reinterpret_cast<const double2 *>(rp + (k + 1) * ncs);
+#pragma unroll
+        for (int ra = 0; ra < R; ++ra)
+          {
+            const double2 v = *reinterpret_cast<const double2 *>(Vs + (ty + 16 * ra) * ldv + k);
+            acc[ra][0]      = fma(v.x, r0.x, acc[ra][0]);
+            acc[ra][1]      = fma(v.x, r0.y, acc[ra][1]);
+            acc[ra][0]      = fma(v.y, r1.x, acc[ra][0]);
+            acc[ra][1]      = fma(v.y, r1.y, acc[ra][1]);
+          }
+      }
+  }
+
   template <int R, int S>
-  __global__ __launch_bounds__(256) void k_solve(const SlodKernelArgs A)
+  __global__ __launch_bounds__(256, solve_min_waves(R)) void k_solve(const SlodKernelArgs A)
   {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const SlodPatchDesc d = A.desc[blockIdx.x];
-    constexpr int       W = 2 * S - 1, BW = 2 * W + 1, NB = 16 * R;
+    constexpr int       W = 2 * S - 1, BW = 2 * W + 1, NB = 16 * R, RBS = NB + 2;
     const int           tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
     const int           m = d.m, L = d.L, nc = d.n_c, n = A.n_sub;
-    const int           mm = A.m_max, ldv = mm + 1, ncs = A.nc_max;
+    const int           mm = A.m_max, ldv = (mm + 1) & ~1, m_even = (m + 1) & ~1;
+    const int           ncs = (A.nc_max + 1) & ~1;
+    const int           ngrp = (nc + kColGroup - 1) / kColGroup;
     const bool          tr  = (d.flags & SLOD_F_TRANSPOSED) != 0;
     const int           npx = d.nx + 1;
 
-    double *Vs     = smem;               // [mm][ldv]  V of the current / previous line
-    double *Rb     = Vs + mm * ldv;      // [mm][ncs]  right-hand side block
-    double *Zp     = Rb + mm * ncs;      // [mm][ncs]  Z of the previous line / X of the next
-    double *rowbuf = Zp + mm * ncs;      // [2][NB]    published pivot rows
-    double *Tb     = rowbuf + 2 * NB;    // [mm][BW]   band of T_l
-    double *Bp     = Tb + mm * BW;       // [mm][BW]   band of B_{l-1}
-    double *Bn     = Bp + mm * BW;       // [mm][BW]   band of B_l
+    // LDS carve-up (doubles); slod_solve_lds_bytes() mirrors it.  gemm_tile reads Vs rows up
+    // to 16R-1 >= m: those land in Rb/Zp (finite or not, the results are discarded), hence
+    // the total is padded to cover NB*ldv.
+    double *Vs     = smem;                      // [ldv][ldv]  V of the line, zero padded
+    double *Rb     = Vs + ldv * ldv;            // [ldv][ncs]  right-hand side block
+    double *Zp     = Rb + ldv * ncs;            // [ldv][ncs]  Z_{l-1} / X_{l+1}
+    double *rowbuf = Zp + ldv * ncs;            // [2][RBS]    published pivot row + 1/pivot
+    double *Tb     = rowbuf + 2 * RBS;          // [mm][BW] band of T_l
+    double *Bp     = Tb + ((mm * BW + 1) & ~1); // [mm][BW] band of B_{l-1}
+    double *Bn     = Bp + ((mm * BW + 1) & ~1); // [mm][BW] band of B_l
+    int    *colk   = reinterpret_cast<int *>(Bn + ((mm * BW + 1) & ~1)); // [2][nc_max]
 
     const double *st    = A.st + (size_t)blockIdx.x * A.st_stride;
     double       *vg    = A.vinv + (size_t)blockIdx.x * A.v_stride;
     double       *xg    = A.xs + (size_t)blockIdx.x * A.x_stride;
-    const size_t  vline = (size_t)mm * mm, xline = (size_t)mm * ncs;
+    const int     ncg   = A.nc_max;
+    const size_t  vline = (size_t)mm * mm, xline = (size_t)mm * ncg;
+
+    for (int idx = tid; idx < ldv * ldv + 2 * ldv * ncs; idx += 256)
+      smem[idx] = 0.0;
+    for (int c = tid; c < nc; c += 256)
+      {
+        int kx, ky;
+        cell_of_col(d, c / S, kx, ky);
+        colk[c]            = kx;
+        colk[A.nc_max + c] = ky;
+      }
 
     // ------------------------------ forward elimination ---------------------------
     for (int l = 0; l < L; ++l)
@@ -218,68 +278,98 @@ namespace
           }
         __syncthreads();
 
-        // S_l in registers
+        // S_l = T_l - B_{l-1}^T V_{l-1} B_{l-1} in registers
         double a[R][R];
 #pragma unroll
-        for (int ra = 0; ra < R; ++ra)
+        for (int rb = 0; rb < R; ++rb)
+          {
+            const int j = tx + 16 * rb;
+            double    bj[BW];
 #pragma unroll
-          for (int rb = 0; rb < R; ++rb)
-            {
-              const int i = ty + 16 * ra, j = tx + 16 * rb;
-              double    v = 0.0;
-              if (i < m && j < m)
-                {
-                  const int o = j - i;
-                  if (o >= -W && o <= W)
-                    v = Tb[i * BW + o + W];
-                  if (l > 0)
-                    {
-                      double acc = 0.0;
-                      for (int e = -W; e <= W; ++e)
-                        {
-                          const int p = i + e;
-                          if (p < 0 || p >= m)
-                            continue;
-                          const double bpi = Bp[p * BW + (W - e)];
-                          double       inner = 0.0;
-                          for (int f = -W; f <= W; ++f)
-                            {
-                              const int q = j + f;
-                              if (q < 0 || q >= m)
-                                continue;
-                              inner += Vs[p * ldv + q] * Bp[q * BW + (W - f)];
-                            }
-                          acc += bpi * inner;
-                        }
-                      v -= acc;
-                    }
-                }
-              a[ra][rb] = v;
-            }
+            for (int f = 0; f < BW; ++f)
+              {
+                const int q = j + f - W;
+                bj[f]       = (l > 0 && j < m && q >= 0 && q < m) ? Bp[q * BW + (2 * W - f)] : 0.0;
+              }
+#pragma unroll
+            for (int ra = 0; ra < R; ++ra)
+              {
+                const int i = ty + 16 * ra;
+                double    v = 0.0;
+                if (i < m && j < m)
+                  {
+                    const int o = j - i;
+                    if (o >= -W && o <= W)
+                      v = Tb[i * BW + o + W];
+                    if (l > 0 && !(A.diag & 1))
+                      {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int e = 0; e < BW; ++e)
+                          {
+                            const int    p  = i + e - W;
+                            const int    pc = min(max(p, 0), m - 1);
+                            const double bi = (p >= 0 && p < m) ? Bp[pc * BW + (2 * W - e)] : 0.0;
+                            double       inner = 0.0;
+#pragma unroll
+                            for (int f = 0; f < BW; ++f)
+                              {
+                                const int qc = min(max(j + f - W, 0), m - 1);
+                                inner        = fma(Vs[pc * ldv + qc], bj[f], inner);
+                              }
+                            acc = fma(bi, inner, acc);
+                          }
+                        v -= acc;
+                      }
+                  }
+                a[ra][rb] = v;
+              }
+          }
 
         // right-hand side block F_l - B_{l-1}^T Z_{l-1}; F = rows of P^T (LOD.cc:478-495)
-        for (int idx = tid; idx < m * nc; idx += 256)
+        if (!(A.diag & 2))
           {
-            const int i = idx / nc, r = idx - i * nc;
-            const int pos = i / S, comp = i - pos * S;
-            const int ix = tr ? l + 1 : pos + 1, iy = tr ? pos + 1 : l + 1;
-            double    v  = A.scale * pt_weight<S>(d, n, A.quirk, ix, iy, comp, r);
-            if (l > 0)
-              for (int e = -W; e <= W; ++e)
-                {
-                  const int p = i + e;
-                  if (p >= 0 && p < m)
-                    v -= Bp[p * BW + (W - e)] * Zp[p * ncs + r];
-                }
-            Rb[i * ncs + r] = v;
+#pragma unroll
+            for (int ra = 0; ra < R; ++ra)
+              {
+                const int i = ty + 16 * ra;
+                if (i >= m)
+                  continue;
+                const int pos = i / S, comp = i - pos * S;
+                const int ix = tr ? l + 1 : pos + 1, iy = tr ? pos + 1 : l + 1;
+                for (int r = tx; r < nc; r += 16)
+                  {
+                    const int jx = ix - colk[r] * n, jy = iy - colk[A.nc_max + r] * n;
+                    double    v  = 0.0;
+                    if (jx >= 0 && jx <= n && jy >= 0 && jy <= n)
+                      {
+                        if (S == 1)
+                          v = A.scale * (((jx == 0 || jx == n) ? 1.0 : 2.0) * ((jy == 0 || jy == n) ? 1.0 : 2.0));
+                        else
+                          v = A.scale * pt_weight<S>(d, n, A.quirk, ix, iy, comp, r);
+                      }
+                    if (l > 0)
+                      {
+#pragma unroll
+                        for (int e = 0; e < BW; ++e)
+                          {
+                            const int p = i + e - W;
+                            if (p >= 0 && p < m)
+                              v = fma(-Bp[p * BW + (2 * W - e)], Zp[p * ncs + r], v);
+                          }
+                      }
+                    Rb[i * ncs + r] = v;
+                  }
+              }
           }
         __syncthreads();
 
-        // symmetric Gauss-Jordan sweep: a <- -S_l^{-1}
-        for (int k = 0; k < m; ++k)
+        // symmetric Gauss-Jordan sweep: a <- -S_l^{-1}.  One barrier per pivot; the chain
+        // per step is: pivot thread rcp -> LDS publish -> barrier -> LDS read -> FMA.
+        for (int k = 0; k < ((A.diag & 4) ? 1 : m); ++k)
           {
             const int ka = k >> 4, kt = k & 15;
-            double   *rbuf = rowbuf + (k & 1) * NB;
+            double   *rbuf = rowbuf + (k & 1) * RBS;
             if (ty == kt)
               {
 #pragma unroll
@@ -289,31 +379,53 @@ namespace
 #pragma unroll
                       for (int rb = 0; rb < R; ++rb)
                         rbuf[tx + 16 * rb] = a[ra][rb];
+                      if (tx == kt)
+                        {
+                          const double piv = a[ra][ra];
+                          rbuf[NB]         = fast_rcp(piv);
+                          if (!(piv > 0.0) && !A.diag)
+                            atomicOr(A.status, 1);
+                        }
                     }
               }
             __syncthreads();
-            const double piv = rbuf[k];
-            if (tid == 0 && !(piv > 0.0))
-              atomicOr(A.status, 1);
-            const double p = 1.0 / piv;
-            double       ri[R], rj[R];
+            const double p = rbuf[NB];
+            double       ri[R], sj[R];
 #pragma unroll
             for (int ra = 0; ra < R; ++ra)
               ri[ra] = rbuf[ty + 16 * ra];
 #pragma unroll
             for (int rb = 0; rb < R; ++rb)
-              rj[rb] = rbuf[tx + 16 * rb];
+              sj[rb] = rbuf[tx + 16 * rb] * p;
 #pragma unroll
             for (int ra = 0; ra < R; ++ra)
 #pragma unroll
               for (int rb = 0; rb < R; ++rb)
-                {
-                  const bool   rowk = (ty == kt) && (ra == ka);
-                  const bool   colk = (tx == kt) && (rb == ka);
-                  const double t    = ri[ra] * rj[rb];
-                  const double upd  = fma(-t, p, a[ra][rb]);
-                  a[ra][rb] = rowk ? (colk ? -p : rj[rb] * p) : (colk ? ri[ra] * p : upd);
-                }
+                a[ra][rb] = fma(-ri[ra], sj[rb], a[ra][rb]);
+            if (ty == kt) // row k: r_j / pivot
+              {
+#pragma unroll
+                for (int ra = 0; ra < R; ++ra)
+                  if (ra == ka)
+                    {
+#pragma unroll
+                      for (int rb = 0; rb < R; ++rb)
+                        a[ra][rb] = sj[rb];
+                    }
+              }
+            if (tx == kt) // column k: r_i / pivot, (k,k): -1/pivot
+              {
+#pragma unroll
+                for (int rb = 0; rb < R; ++rb)
+                  if (rb == ka)
+                    {
+#pragma unroll
+                      for (int ra = 0; ra < R; ++ra)
+                        a[ra][rb] = ri[ra] * p;
+                      if (ty == kt)
+                        a[rb][rb] = -p;
+                    }
+              }
           }
 
         // V_l = -a  -> LDS (next sandwich, GEMM) and global workspace (backward pass)
@@ -327,39 +439,37 @@ namespace
                 {
                   const double v  = -a[ra][rb];
                   Vs[i * ldv + j] = v;
-                  vg[(size_t)l * vline + (size_t)i * mm + j] = v;
+                  if (!(A.diag & 32))
+                    vg[(size_t)l * vline + (size_t)i * mm + j] = v;
                 }
             }
         __syncthreads();
 
         // Z_l = V_l R_l
-        for (int r = tx; r < nc; r += 16)
-          {
-            double acc[R];
+        if (!(A.diag & 8))
+          for (int g = 0; g < ngrp; ++g)
+            {
+              const int col0 = g * kColGroup + 2 * tx;
+              if (col0 >= ncs)
+                continue;
+              double acc[R][2];
+              gemm_tile<R>(Vs, ldv, Rb, ncs, m_even, ty, col0, acc);
 #pragma unroll
-            for (int ra = 0; ra < R; ++ra)
-              acc[ra] = 0.0;
-            for (int k = 0; k < m; ++k)
-              {
-                const double rk = Rb[k * ncs + r];
+              for (int ra = 0; ra < R; ++ra)
+                {
+                  const int i = ty + 16 * ra;
+                  if (i < m)
+                    {
 #pragma unroll
-                for (int ra = 0; ra < R; ++ra)
-                  {
-                    const int i = ty + 16 * ra;
-                    acc[ra] += ((i < m) ? Vs[i * ldv + k] : 0.0) * rk;
-                  }
-              }
-#pragma unroll
-            for (int ra = 0; ra < R; ++ra)
-              {
-                const int i = ty + 16 * ra;
-                if (i < m)
-                  {
-                    Zp[i * ncs + r] = acc[ra];
-                    xg[(size_t)l * xline + (size_t)i * ncs + r] = acc[ra];
-                  }
-              }
-          }
+                      for (int c = 0; c < 2; ++c)
+                        if (col0 + c < nc)
+                          {
+                            Zp[i * ncs + col0 + c]                              = acc[ra][c];
+                            xg[(size_t)l * xline + (size_t)i * ncg + col0 + c] = acc[ra][c];
+                          }
+                    }
+                }
+            }
         double *t = Bp;
         Bp        = Bn;
         Bn        = t;
@@ -368,59 +478,101 @@ namespace
     __syncthreads();
 
     // ------------------------------ backward substitution -------------------------
-    // Zp holds X_{L-1} = Z_{L-1}
-    for (int l = L - 2; l >= 0; --l)
+    // Zp holds X_{L-1} = Z_{L-1}.  V_l is prefetched from the workspace one line ahead.
+    double vpre[R][R];
+    if (L >= 2 && !(A.diag & 16))
+      {
+#pragma unroll
+        for (int ra = 0; ra < R; ++ra)
+#pragma unroll
+          for (int rb = 0; rb < R; ++rb)
+            {
+              const int i = ty + 16 * ra, j = tx + 16 * rb;
+              vpre[ra][rb] = (i < m && j < m) ? vg[(size_t)(L - 2) * vline + (size_t)i * mm + j] : 0.0;
+            }
+      }
+    for (int l = (A.diag & 16) ? -1 : L - 2; l >= 0; --l)
       {
         for (int idx = tid; idx < m * BW; idx += 256)
           {
             const int i = idx / BW, o = idx - i * BW - W;
             Bn[idx]     = coupling<S>(st, A.nn_max, npx, tr, m, l, i, 1, o);
           }
-        for (int idx = tid; idx < m * m; idx += 256)
+#pragma unroll
+        for (int ra = 0; ra < R; ++ra)
+#pragma unroll
+          for (int rb = 0; rb < R; ++rb)
+            {
+              const int i = ty + 16 * ra, j = tx + 16 * rb;
+              if (i < m && j < m)
+                Vs[i * ldv + j] = vpre[ra][rb];
+            }
+        if (l > 0)
           {
-            const int i = idx / m, j = idx - i * m;
-            Vs[i * ldv + j] = vg[(size_t)l * vline + (size_t)i * mm + j];
-          }
-        __syncthreads();
-        for (int idx = tid; idx < m * nc; idx += 256)
-          {
-            const int i = idx / nc, r = idx - i * nc;
-            double    v = 0.0;
-            for (int o = -W; o <= W; ++o)
-              {
-                const int p = i + o;
-                if (p >= 0 && p < m)
-                  v += Bn[i * BW + o + W] * Zp[p * ncs + r];
-              }
-            Rb[i * ncs + r] = v;
-          }
-        __syncthreads();
-        for (int r = tx; r < nc; r += 16)
-          {
-            double acc[R];
 #pragma unroll
             for (int ra = 0; ra < R; ++ra)
-              acc[ra] = 0.0;
-            for (int k = 0; k < m; ++k)
-              {
-                const double rk = Rb[k * ncs + r];
 #pragma unroll
-                for (int ra = 0; ra < R; ++ra)
+              for (int rb = 0; rb < R; ++rb)
+                {
+                  const int i = ty + 16 * ra, j = tx + 16 * rb;
+                  vpre[ra][rb] = (i < m && j < m) ? vg[(size_t)(l - 1) * vline + (size_t)i * mm + j] : 0.0;
+                }
+          }
+        __syncthreads();
+        // Y = B_l X_{l+1}
+#pragma unroll
+        for (int ra = 0; ra < R; ++ra)
+          {
+            const int i = ty + 16 * ra;
+            if (i >= m)
+              continue;
+            for (int r = tx; r < nc; r += 16)
+              {
+                double v = 0.0;
+#pragma unroll
+                for (int o = 0; o < BW; ++o)
                   {
-                    const int i = ty + 16 * ra;
-                    acc[ra] += ((i < m) ? Vs[i * ldv + k] : 0.0) * rk;
+                    const int p = i + o - W;
+                    if (p >= 0 && p < m)
+                      v = fma(Bn[i * BW + o], Zp[p * ncs + r], v);
                   }
+                Rb[i * ncs + r] = v;
               }
+          }
+        __syncthreads();
+        // X_l = Z_l - V_l Y
+        for (int g = 0; g < ngrp; ++g)
+          {
+            const int col0 = g * kColGroup + 2 * tx;
+            if (col0 >= ncs)
+              continue;
+            double zl[R][2];
+#pragma unroll
+            for (int ra = 0; ra < R; ++ra)
+#pragma unroll
+              for (int c = 0; c < 2; ++c)
+                {
+                  const int i = ty + 16 * ra;
+                  zl[ra][c]   = (i < m && col0 + c < nc)
+                                  ? xg[(size_t)l * xline + (size_t)i * ncg + col0 + c]
+                                  : 0.0;
+                }
+            double acc[R][2];
+            gemm_tile<R>(Vs, ldv, Rb, ncs, m_even, ty, col0, acc);
 #pragma unroll
             for (int ra = 0; ra < R; ++ra)
               {
                 const int i = ty + 16 * ra;
                 if (i < m)
                   {
-                    const size_t gi = (size_t)l * xline + (size_t)i * ncs + r;
-                    const double x  = xg[gi] - acc[ra];
-                    xg[gi]          = x;
-                    Zp[i * ncs + r] = x;
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+                      if (col0 + c < nc)
+                        {
+                          const double x = zl[ra][c] - acc[ra][c];
+                          xg[(size_t)l * xline + (size_t)i * ncg + col0 + c] = x;
+                          Zp[i * ncs + col0 + c]                              = x;
+                        }
                   }
               }
           }
@@ -466,6 +618,14 @@ namespace
     ix = t99 ? bi : ((l99 && bi == 0) ? 0 : d.nx);
   }
 
+  // The SLOD selection needs  d = -(BD')^+ b0  (LOD.cc:656-671) and, only if ||d||_inf >= 0.5
+  // or a singular value falls under the 1e-15 cutoff, the singular triplets of BD' for the
+  // truncation loop (LOD.cc:703-725).  So: Householder QR of [BD' | b0] in LDS first.  With
+  // R (n x n) and c = Q^T b0:  d = -R^{-1} c.  cond(R) <= ||R||_F ||R^{-1}||_F =: kF is a
+  // rigorous bound, so kF^2 < 1e14 proves that no singular value of G = R^T R is cut, and
+  // ||d||_inf < 0.5 (with a 1e-9 guard band) proves the loop removes nothing: the fast path
+  // takes exactly the reference's decisions.  Otherwise a one-sided Jacobi SVD of R (same
+  // singular values / right vectors as BD', u_j^T g = (R v_j).c) replays the loop literally.
   template <int S>
   __global__ __launch_bounds__(256) void k_select(const SlodKernelArgs A, int nb_max, int nf_max)
   {
@@ -479,22 +639,24 @@ namespace
     const bool          lod = (d.flags & SLOD_F_LOD) != 0;
     const int           npx = d.nx + 1, nn = npx * (d.ny + 1), nf = S * nn;
 
-    double *Ms   = smem;                 // [ncm][ldm]  (later: D)
-    double *Vj   = Ms + ncm * ldm;       // [ncm][ncm]  Jacobi rotations
-    double *BD   = Vj + ncm * ncm;       // [nb_max][ncm]
-    double *phis = BD + (size_t)nb_max * ncm; // [nf_max]
-    double *sig  = phis + nf_max;        // [ncm]
+    double *Ms   = smem;                 // [ncm][ldm]  M, then D = M^-1
+    double *Vj   = Ms + ncm * ldm;       // [ncm][ncm]  R^-1 / Jacobi rotations
+    double *BD   = Vj + ncm * ncm;       // [nb_max][ncm]  (nb_max = buffer rows, see TSQR below)
+    double *phis = BD;                   // [nf_max] aliases BD (dead once gamma is known)
+    double *sig  = BD + max(nb_max * ncm, nf_max); // [ncm]
     double *utg  = sig + ncm;
     double *gam  = utg + ncm;
     double *cvec = gam + ncm;
     double *rowk = cvec + ncm;           // [ncm]
     double *red  = rowk + ncm;           // [8]
-    int    *ord  = reinterpret_cast<int *>(red + 8); // [ncm]
-    int    *flag = ord + ncm;            // [2]
+    int    *colk = reinterpret_cast<int *>(red + 8); // [2][ncm] cell of column
+    int    *ord  = colk + 2 * ncm;       // [ncm]
+    int    *flag = ord + ncm;            // [4]
 
     const double *st    = A.st + (size_t)blockIdx.x * A.st_stride;
     const double *xg    = A.xs + (size_t)blockIdx.x * A.x_stride;
     const size_t  xline = (size_t)mm * ncs;
+    const int     wave = tid >> 6, lane = tid & 63, grp = tid >> 4, l16 = tid & 15;
 
     // row of X for dof (ix,iy,comp), nullptr on the patch boundary (X_B = 0, LOD.cc:512-518)
     auto xrow = [&](int ix, int iy, int comp) -> const double * {
@@ -503,42 +665,93 @@ namespace
       const int l = tr ? ix - 1 : iy - 1, pos = tr ? iy - 1 : ix - 1;
       return xg + (size_t)l * xline + (size_t)(pos * S + comp) * ncs;
     };
+    // entry of the un-zeroed P^T / (h^2/4)
+    auto ptw = [&](int ix, int iy, int comp, int col) -> double {
+      if (S == 1)
+        {
+          const int jx = ix - colk[col] * n, jy = iy - colk[ncm + col] * n;
+          if (jx < 0 || jx > n || jy < 0 || jy > n)
+            return 0.0;
+          return ((jx == 0 || jx == n) ? 1.0 : 2.0) * ((jy == 0 || jy == n) ? 1.0 : 2.0);
+        }
+      return pt_weight<S>(d, n, A.quirk, ix, iy, comp, col);
+    };
+    auto block_sum = [&](double v) -> double { // all threads get the sum
+      for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_xor(v, off, 64);
+      __syncthreads();
+      if (lane == 0)
+        red[wave] = v;
+      __syncthreads();
+      return red[0] + red[1] + red[2] + red[3];
+    };
 
-    // ---- M = P^T X / H^dim (LOD.cc:548-551)
-    for (int idx = tid; idx < nc * nc; idx += 256)
+    for (int c = tid; c < nc; c += 256)
+      {
+        int kx, ky;
+        cell_of_col(d, c / S, kx, ky);
+        colk[c]       = kx;
+        colk[ncm + c] = ky;
+      }
+    __syncthreads();
+
+    // ---- M = P^T X / H^dim (LOD.cc:548-551).  X rows come from the global workspace: the
+    //      inner loop has no control dependence (clamped address, zero weight on the patch
+    //      boundary where X = 0) so its n+1 loads are in flight together.
+    for (int idx = tid; idx < ((A.diag & 64) ? 0 : nc * nc); idx += 256)
       {
         const int a = idx / nc, b = idx - a * nc;
-        int       kx, ky;
-        cell_of_col(d, a / S, kx, ky);
-        double acc = 0.0;
-        for (int jy = 0; jy <= n; ++jy)
-          for (int jx = 0; jx <= n; ++jx)
-            {
-              const int ix = kx * n + jx, iy = ky * n + jy;
-#pragma unroll
-              for (int c = 0; c < S; ++c)
+        const int kx = colk[a], ky = colk[ncm + a];
+        double    acc = 0.0;
+        if (S == 1 || !A.quirk)
+          {
+            const int ca = a % S;
+            for (int jy = 0; jy <= n; ++jy)
+              {
+                const int iy = ky * n + jy;
+                if (iy <= 0 || iy >= d.ny)
+                  continue;
+                double part = 0.0;
+#pragma unroll 9
+                for (int jx = 0; jx <= n; ++jx)
+                  {
+                    const int    ix  = kx * n + jx;
+                    const int    ixc = min(max(ix, 1), d.nx - 1);
+                    const int    l = tr ? ixc - 1 : iy - 1, pos = tr ? iy - 1 : ixc - 1;
+                    const double x = xg[(size_t)l * xline + (size_t)(pos * S + ca) * ncs + b];
+                    const double w = (ix > 0 && ix < d.nx) ? ((jx == 0 || jx == n) ? 1.0 : 2.0) : 0.0;
+                    part           = fma(w, x, part);
+                  }
+                acc = fma((jy == 0 || jy == n) ? 1.0 : 2.0, part, acc);
+              }
+          }
+        else
+          {
+            for (int jy = 0; jy <= n; ++jy)
+              for (int jx = 0; jx <= n; ++jx)
                 {
-                  const double w = pt_weight<S>(d, n, A.quirk, ix, iy, c, a);
-                  if (w != 0.0)
+                  const int ix = kx * n + jx, iy = ky * n + jy;
+#pragma unroll
+                  for (int c = 0; c < S; ++c)
                     {
                       const double *xr = xrow(ix, iy, c);
                       if (xr)
-                        acc += w * xr[b];
+                        acc = fma(pt_weight<S>(d, n, A.quirk, ix, iy, c, a), xr[b], acc);
                     }
                 }
-            }
+          }
         Ms[a * ldm + b] = acc * A.scale * A.invH2;
       }
     __syncthreads();
 
     // ---- D = M^{-1} (LOD.cc:553) by the symmetric sweep; M is SPD
-    for (int k = 0; k < nc; ++k)
+    for (int k = 0; k < ((A.diag & 128) ? 0 : nc); ++k)
       {
         for (int j = tid; j < nc; j += 256)
           rowk[j] = Ms[k * ldm + j];
         __syncthreads();
         const double piv = rowk[k];
-        if (tid == 0 && !(piv > 0.0))
+        if (tid == 0 && !(piv > 0.0) && !A.diag)
           atomicOr(A.status, 2);
         const double p = 1.0 / piv;
         for (int idx = tid; idx < nc * nc; idx += 256)
@@ -570,174 +783,299 @@ namespace
           gam[j] = (j == dsel) ? 1.0 : 0.0;
         if (!lod)
           {
-            // ---- BD = (S_BI X_I - P^T_B) D (LOD.cc:609-618); stencil rows instead of the
-            //      dense S_boundary
-            for (int idx = tid; idx < nb * nc; idx += 256)
+            // ---- BD = (S_BI X_I - P^T_B) D (LOD.cc:609-618), built in row chunks that fit the
+            //      LDS buffer (nbuf rows) and reduced by Householder QR chunk after chunk
+            //      (TSQR): after every chunk the top nn1 rows hold the R factor of all rows
+            //      seen so far and c = Q^T b0 sits in column dsel.
+            const int nn1 = nc - 1; // columns of BD' = BD without column dsel
+            auto      cix = [&](int j) { return j < dsel ? j : j + 1; };
+            const int nbuf = nb_max;
+            int       nr   = 0;     // rows of the matrix the SVD fallback works on
+            bool      need_svd = true, singular = false, did_qr = false;
+            int       filled = 0;
+            for (int r0 = 0; r0 < nb;)
               {
-                const int bi = idx / nc, c = idx - bi * nc;
-                const int bn = bi / S, ca = bi - bn * S;
-                int       ix, iy;
-                boundary_node(d, bn, ix, iy);
-                double acc = -A.scale * pt_weight<S>(d, n, A.quirk, ix, iy, ca, c);
-                for (int dy = -1; dy <= 1; ++dy)
-                  for (int dx = -1; dx <= 1; ++dx)
-                    {
-                      const int jx = ix + dx, jy = iy + dy;
-                      if (jx <= 0 || jx >= d.nx || jy <= 0 || jy >= d.ny)
-                        continue;
-                      const int dir = (dy + 1) * 3 + dx + 1;
-#pragma unroll
-                      for (int cb = 0; cb < S; ++cb)
-                        acc += st[(size_t)((dir * S + ca) * S + cb) * A.nn_max + ix + iy * npx] *
-                               xrow(jx, jy, cb)[c];
-                    }
-                BD[bi * ncm + c] = acc;
-              }
-            __syncthreads();
-            // BD <- BD * D, one wave per row, row held across lanes (nc <= 64)
-            {
-              const int wave = tid >> 6, lane = tid & 63;
-              for (int bi = wave; bi < nb; bi += 4)
-                {
-                  const double mine = (lane < nc) ? BD[bi * ncm + lane] : 0.0;
-                  double       acc  = 0.0;
-                  for (int j = 0; j < nc; ++j)
-                    {
-                      const double bj = __shfl(mine, j, 64);
-                      acc += bj * ((lane < nc) ? Ds[j * ldm + lane] : 0.0);
-                    }
-                  if (lane < nc)
-                    BD[bi * ncm + lane] = acc;
-                }
-            }
-            // ---- one-sided Jacobi SVD of BD' = BD without column dsel (LOD.cc:656-667:
-            //      sigma(G) = sigma(BD')^2, same right singular vectors)
-            const int nn1 = nc - 1;           // columns of BD'
-            const int nev = (nn1 + 1) & ~1;   // rounded up to even
-            for (int idx = tid; idx < nn1 * nn1; idx += 256)
-              Vj[idx] = ((idx / nn1) == (idx % nn1)) ? 1.0 : 0.0;
-            __syncthreads();
-            const int grp = tid >> 4, l16 = tid & 15;
-            for (int sweep = 0; sweep < 40; ++sweep)
-              {
-                if (tid == 0)
-                  flag[0] = 0;
-                __syncthreads();
-                for (int round = 0; round < nev - 1; ++round)
+                const int take = min(nb - r0, nbuf - filled);
+                // stencil rows instead of the dense S_boundary
+                for (int idx = tid; idx < ((A.diag & 256) ? 0 : take * nc); idx += 256)
                   {
-                    for (int pr = grp; pr < nev / 2; pr += 16)
+                    const int br = idx / nc, c = idx - br * nc;
+                    const int bi = r0 + br;
+                    const int bn = bi / S, ca = bi - bn * S;
+                    int       ix, iy;
+                    boundary_node(d, bn, ix, iy);
+                    double acc = -A.scale * ptw(ix, iy, ca, c);
+#pragma unroll
+                    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                      for (int dx = -1; dx <= 1; ++dx)
+                        {
+                          const int  jx = ix + dx, jy = iy + dy;
+                          const bool in = (jx > 0 && jx < d.nx && jy > 0 && jy < d.ny);
+                          const int  jxc = min(max(jx, 1), d.nx - 1), jyc = min(max(jy, 1), d.ny - 1);
+                          const int  dir = (dy + 1) * 3 + dx + 1;
+                          const int  l = tr ? jxc - 1 : jyc - 1, pos = tr ? jyc - 1 : jxc - 1;
+#pragma unroll
+                          for (int cb = 0; cb < S; ++cb)
+                            {
+                              const double sv = in ? st[(size_t)((dir * S + ca) * S + cb) * A.nn_max + ix + iy * npx] : 0.0;
+                              acc = fma(sv, xg[(size_t)l * xline + (size_t)(pos * S + cb) * ncs + c], acc);
+                            }
+                        }
+                    BD[(filled + br) * ncm + c] = acc;
+                  }
+                __syncthreads();
+                // rows <- rows * D, one wave per row, row held across lanes (nc <= 64)
+                for (int br = wave; br < take; br += 4)
+                  {
+                    const int    row  = filled + br;
+                    const double mine = (lane < nc) ? BD[row * ncm + lane] : 0.0;
+                    double       acc  = 0.0;
+                    for (int j = 0; j < nc; ++j)
                       {
-                        int pa, pb;
-                        if (pr == 0)
+                        const double bj = __shfl(mine, j, 64);
+                        acc             = fma(bj, (lane < nc) ? Ds[j * ldm + lane] : 0.0, acc);
+                      }
+                    if (lane < nc)
+                      BD[row * ncm + lane] = acc;
+                  }
+                __syncthreads();
+                r0 += take;
+                const int rows = filled + take;
+                nr             = rows;
+                if (rows < nn1 || (A.diag & 512))
+                  {
+                    filled = rows; // fewer rows than columns so far
+                    if (filled >= nbuf)
+                      break;       // cannot happen: nbuf > nn1
+                    continue;
+                  }
+                // ---- Householder QR of the rows x [BD' | b0] block, in place
+                did_qr = true;
+                for (int k = 0; k < nn1; ++k)
+                  {
+                    const int ck = cix(k);
+                    double    part = 0.0;
+                    for (int r = k + tid; r < rows; r += 256)
+                      {
+                        const double x = BD[r * ncm + ck];
+                        part           = fma(x, x, part);
+                      }
+                    const double sigma = block_sum(part);
+                    if (!(sigma > 0.0))
+                      {
+                        if (r0 >= nb)
+                          singular = true; // zero column: rank deficient, replay via the SVD
+                        continue;
+                      }
+                    const double x0    = BD[k * ncm + ck];
+                    const double alpha = (x0 >= 0.0) ? -sqrt(sigma) : sqrt(sigma);
+                    const double v0    = x0 - alpha;
+                    const double beta  = 1.0 / (sigma - alpha * x0); // 2 / v^T v
+                    __syncthreads();
+                    // apply H = I - beta v v^T to the trailing columns and to b0
+                    for (int t = grp; t < nn1 - k; t += 16)
+                      {
+                        const int cj = (t == nn1 - k - 1) ? dsel : cix(k + 1 + t);
+                        double    s  = 0.0;
+                        for (int r = k + l16; r < rows; r += 16)
                           {
-                            pa = nev - 1;
-                            pb = round;
+                            const double vr = (r == k) ? v0 : BD[r * ncm + ck];
+                            s               = fma(vr, BD[r * ncm + cj], s);
                           }
-                        else
+                        s = group16_sum(s) * beta;
+                        for (int r = k + l16; r < rows; r += 16)
                           {
-                            pa = (round + pr) % (nev - 1);
-                            pb = (round - pr + (nev - 1)) % (nev - 1);
+                            const double vr   = (r == k) ? v0 : BD[r * ncm + ck];
+                            BD[r * ncm + cj] = fma(-s, vr, BD[r * ncm + cj]);
                           }
-                        if (pa >= nn1 || pb >= nn1)
-                          continue;
-                        const int p = pa < pb ? pa : pb, q = pa < pb ? pb : pa;
-                        const int cp = p < dsel ? p : p + 1, cq = q < dsel ? q : q + 1;
-                        double    app = 0, aqq = 0, apq = 0;
-                        for (int r = l16; r < nb; r += 16)
-                          {
-                            const double wp = BD[r * ncm + cp], wq = BD[r * ncm + cq];
-                            app += wp * wp;
-                            aqq += wq * wq;
-                            apq += wp * wq;
-                          }
-                        app = group16_sum(app);
-                        aqq = group16_sum(aqq);
-                        apq = group16_sum(apq);
-                        if (apq == 0.0 || fabs(apq) <= 1e-15 * sqrt(app * aqq))
-                          continue;
-                        const double zeta = (aqq - app) / (2.0 * apq);
-                        const double t =
-                          (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                        const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
-                        for (int r = l16; r < nb; r += 16)
-                          {
-                            const double wp = BD[r * ncm + cp], wq = BD[r * ncm + cq];
-                            BD[r * ncm + cp] = cs * wp - sn * wq;
-                            BD[r * ncm + cq] = sn * wp + cs * wq;
-                          }
-                        for (int r = l16; r < nn1; r += 16)
-                          {
-                            const double vp = Vj[r * nn1 + p], vq = Vj[r * nn1 + q];
-                            Vj[r * nn1 + p] = cs * vp - sn * vq;
-                            Vj[r * nn1 + q] = sn * vp + cs * vq;
-                          }
-                        if (l16 == 0)
-                          flag[0] = 1;
                       }
                     __syncthreads();
+                    if (tid == 0)
+                      BD[k * ncm + ck] = alpha;
+                    for (int r = k + 1 + tid; r < rows; r += 256)
+                      BD[r * ncm + ck] = 0.0;
+                    __syncthreads();
                   }
-                const int any = flag[0];
-                __syncthreads();
-                if (!any)
-                  break;
+                filled = nn1;
+                nr     = nn1;
               }
-            // singular values of G and u_j^T g = w_j . b0
-            for (int j = tid; j < nn1; j += 256)
+            if (did_qr && !(A.diag & 512))
               {
-                const int cj = j < dsel ? j : j + 1;
-                double    ss = 0, wb = 0;
-                for (int r = 0; r < nb; ++r)
+                if (!singular)
                   {
-                    const double w = BD[r * ncm + cj];
-                    ss += w * w;
-                    wb += w * BD[r * ncm + dsel];
-                  }
-                sig[j] = ss;
-                utg[j] = wb;
-              }
-            __syncthreads();
-            if (tid == 0)
-              {
-                // descending sigma, pseudo-inverse cutoff (LOD.cc:667), d = -G^+ g, then the
-                // 0.5-loop (LOD.cc:703-725).  gam[] doubles as d_i storage (others order).
-                for (int j = 0; j < nn1; ++j)
-                  ord[j] = j;
-                for (int a2 = 1; a2 < nn1; ++a2)
-                  {
-                    const int o = ord[a2];
-                    int       b = a2 - 1;
-                    while (b >= 0 && sig[ord[b]] < sig[o])
+                    // R^{-1} by columns (thread j solves R x = e_j), Frobenius norms, d = -R^{-1} c
+                    double fr = 0.0, fi = 0.0;
+                    if (tid < nn1)
                       {
-                        ord[b + 1] = ord[b];
-                        --b;
+                        const int j = tid;
+                        for (int i = 0; i <= j; ++i)
+                          {
+                            const double r = BD[i * ncm + cix(j)];
+                            fr             = fma(r, r, fr);
+                          }
+                        Vj[j * nn1 + j] = 1.0 / BD[j * ncm + cix(j)];
+                        for (int i = j - 1; i >= 0; --i)
+                          {
+                            double s = 0.0;
+                            for (int k2 = i + 1; k2 <= j; ++k2)
+                              s = fma(BD[i * ncm + cix(k2)], Vj[k2 * nn1 + j], s);
+                            Vj[i * nn1 + j] = -s / BD[i * ncm + cix(i)];
+                          }
+                        for (int i = 0; i <= j; ++i)
+                          fi = fma(Vj[i * nn1 + j], Vj[i * nn1 + j], fi);
                       }
-                    ord[b + 1] = o;
+                    const double nr2 = block_sum(fr), ni2 = block_sum(fi);
+                    double       del = 0.0;
+                    if (tid < nn1)
+                      {
+                        for (int j = tid; j < nn1; ++j)
+                          del = fma(-Vj[tid * nn1 + j], BD[j * ncm + dsel], del);
+                        rowk[tid] = del;
+                      }
+                    double dmax = fabs(del);
+                    for (int off = 32; off > 0; off >>= 1)
+                      dmax = fmax(dmax, __shfl_xor(dmax, off, 64));
+                    __syncthreads();
+                    if (lane == 0)
+                      red[4 + wave] = dmax;
+                    __syncthreads();
+                    const double dinf = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+                    if (nr2 * ni2 < 1e14 && dinf < 0.5 - 1e-9)
+                      {
+                        need_svd = false;
+                        if (tid < nn1)
+                          gam[cix(tid)] = rowk[tid];
+                      }
                   }
-                const double s0 = sig[ord[0]];
-                double      *del = rowk; // scratch [nn1]
-                for (int a2 = 0; a2 < nn1; ++a2)
-                  del[a2] = 0.0;
-                for (int r = 0; r < nn1; ++r)
+              }
+            if (need_svd && !(A.diag & 512))
+              {
+                // ---- one-sided Jacobi SVD on the nr x nn1 matrix in BD (R after the QR, BD'
+                //      itself if nb < nn1); sigma(G) = sigma^2, u_j^T g = w_j . b0
+                const int nev = (nn1 + 1) & ~1;
+                for (int idx = tid; idx < nn1 * nn1; idx += 256)
+                  Vj[idx] = ((idx / nn1) == (idx % nn1)) ? 1.0 : 0.0;
+                __syncthreads();
+                for (int sweep = 0; sweep < 40; ++sweep)
                   {
-                    const int j = ord[r];
-                    utg[j]      = (sig[j] > 1e-15 * s0) ? utg[j] / sig[j] : 0.0;
-                    for (int a2 = 0; a2 < nn1; ++a2)
-                      del[a2] -= Vj[a2 * nn1 + j] * utg[j];
-                  }
-                for (int r = nn1 - 1; r >= 0; --r)
-                  {
-                    double dinf = 0.0;
-                    for (int a2 = 0; a2 < nn1; ++a2)
-                      dinf = fmax(dinf, fabs(del[a2]));
-                    if (dinf < 0.5)
+                    if (tid == 0)
+                      flag[0] = 0;
+                    __syncthreads();
+                    for (int round = 0; round < nev - 1; ++round)
+                      {
+                        for (int pr = grp; pr < nev / 2; pr += 16)
+                          {
+                            int pa, pb;
+                            if (pr == 0)
+                              {
+                                pa = nev - 1;
+                                pb = round;
+                              }
+                            else
+                              {
+                                pa = (round + pr) % (nev - 1);
+                                pb = (round - pr + (nev - 1)) % (nev - 1);
+                              }
+                            if (pa >= nn1 || pb >= nn1)
+                              continue;
+                            const int p = pa < pb ? pa : pb, q = pa < pb ? pb : pa;
+                            const int cp = cix(p), cq = cix(q);
+                            double    app = 0, aqq = 0, apq = 0;
+                            for (int r = l16; r < nr; r += 16)
+                              {
+                                const double wp = BD[r * ncm + cp], wq = BD[r * ncm + cq];
+                                app = fma(wp, wp, app);
+                                aqq = fma(wq, wq, aqq);
+                                apq = fma(wp, wq, apq);
+                              }
+                            app = group16_sum(app);
+                            aqq = group16_sum(aqq);
+                            apq = group16_sum(apq);
+                            if (apq == 0.0 || fabs(apq) <= 1e-15 * sqrt(app * aqq))
+                              continue;
+                            const double zeta = (aqq - app) / (2.0 * apq);
+                            const double t =
+                              (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                            const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+                            for (int r = l16; r < nr; r += 16)
+                              {
+                                const double wp = BD[r * ncm + cp], wq = BD[r * ncm + cq];
+                                BD[r * ncm + cp] = cs * wp - sn * wq;
+                                BD[r * ncm + cq] = sn * wp + cs * wq;
+                              }
+                            for (int r = l16; r < nn1; r += 16)
+                              {
+                                const double vp = Vj[r * nn1 + p], vq = Vj[r * nn1 + q];
+                                Vj[r * nn1 + p] = cs * vp - sn * vq;
+                                Vj[r * nn1 + q] = sn * vp + cs * vq;
+                              }
+                            if (l16 == 0)
+                              flag[0] = 1;
+                          }
+                        __syncthreads();
+                      }
+                    const int any = flag[0];
+                    __syncthreads();
+                    if (!any)
                       break;
-                    const int j = ord[r];
-                    for (int a2 = 0; a2 < nn1; ++a2)
-                      del[a2] += Vj[a2 * nn1 + j] * utg[j];
                   }
-                for (int j = 0, jj = 0; j < nc; ++j)
-                  if (j != dsel)
-                    gam[j] = del[jj++];
+                for (int j = tid; j < nn1; j += 256)
+                  {
+                    const int cj = cix(j);
+                    double    ss = 0, wb = 0;
+                    for (int r = 0; r < nr; ++r)
+                      {
+                        const double w = BD[r * ncm + cj];
+                        ss             = fma(w, w, ss);
+                        wb             = fma(w, BD[r * ncm + dsel], wb);
+                      }
+                    sig[j] = ss;
+                    utg[j] = wb;
+                  }
+                __syncthreads();
+                if (tid == 0)
+                  {
+                    // descending sigma, pseudo-inverse cutoff (LOD.cc:667), d = -G^+ g, then the
+                    // 0.5-loop (LOD.cc:703-725)
+                    for (int j = 0; j < nn1; ++j)
+                      ord[j] = j;
+                    for (int a2 = 1; a2 < nn1; ++a2)
+                      {
+                        const int o = ord[a2];
+                        int       b = a2 - 1;
+                        while (b >= 0 && sig[ord[b]] < sig[o])
+                          {
+                            ord[b + 1] = ord[b];
+                            --b;
+                          }
+                        ord[b + 1] = o;
+                      }
+                    const double s0  = sig[ord[0]];
+                    double      *del = rowk;
+                    for (int a2 = 0; a2 < nn1; ++a2)
+                      del[a2] = 0.0;
+                    for (int r = 0; r < nn1; ++r)
+                      {
+                        const int j = ord[r];
+                        utg[j]      = (sig[j] > 1e-15 * s0) ? utg[j] / sig[j] : 0.0;
+                        for (int a2 = 0; a2 < nn1; ++a2)
+                          del[a2] -= Vj[a2 * nn1 + j] * utg[j];
+                      }
+                    for (int r = nn1 - 1; r >= 0; --r)
+                      {
+                        double dinf = 0.0;
+                        for (int a2 = 0; a2 < nn1; ++a2)
+                          dinf = fmax(dinf, fabs(del[a2]));
+                        if (dinf < 0.5)
+                          break;
+                        const int j = ord[r];
+                        for (int a2 = 0; a2 < nn1; ++a2)
+                          del[a2] += Vj[a2 * nn1 + j] * utg[j];
+                      }
+                    for (int j = 0; j < nn1; ++j)
+                      gam[cix(j)] = del[j];
+                  }
               }
           }
         __syncthreads();
@@ -746,13 +1084,13 @@ namespace
           {
             double acc = 0.0;
             for (int j = 0; j < nc; ++j)
-              acc += Ds[i * ldm + j] * gam[j];
+              acc = fma(Ds[i * ldm + j], gam[j], acc);
             cvec[i] = acc;
           }
         __syncthreads();
         // ---- phi = X c, zero on the boundary (LOD.cc:745-750), l2-normalised (LOD.cc:752)
         double ssq = 0.0;
-        for (int dof = tid; dof < nf; dof += 256)
+        for (int dof = tid; dof < ((A.diag & 1024) ? 0 : nf); dof += 256)
           {
             const int     node = dof / S, comp = dof - node * S;
             const int     ix = node % npx, iy = node / npx;
@@ -760,16 +1098,11 @@ namespace
             double        acc = 0.0;
             if (xr)
               for (int j = 0; j < nc; ++j)
-                acc += xr[j] * cvec[j];
+                acc = fma(xr[j], cvec[j], acc);
             phis[dof] = acc;
-            ssq += acc * acc;
+            ssq       = fma(acc, acc, ssq);
           }
-        for (int off = 32; off > 0; off >>= 1)
-          ssq += __shfl_xor(ssq, off, 64);
-        if ((tid & 63) == 0)
-          red[tid >> 6] = ssq;
-        __syncthreads();
-        const double nrm = sqrt(red[0] + red[1] + red[2] + red[3]);
+        const double nrm = sqrt(block_sum(ssq));
         double      *ob  = A.basis + d.out_off + (size_t)dsel * nf;
         double      *op  = A.premult + d.out_off + (size_t)dsel * nf;
         for (int dof = tid; dof < nf; dof += 256)
@@ -780,7 +1113,7 @@ namespace
           }
         __syncthreads();
         // ---- psi = A_semi phi: identity rows on id-0 dofs (LOD.cc:537-541,758-765)
-        for (int dof = tid; dof < nf; dof += 256)
+        for (int dof = tid; dof < ((A.diag & 2048) ? 0 : nf); dof += 256)
           {
             const int  node = dof / S, comp = dof - node * S;
             const int  ix = node % npx, iy = node / npx;
@@ -801,8 +1134,8 @@ namespace
                       const int dir = (dy + 1) * 3 + dx + 1;
 #pragma unroll
                       for (int cb = 0; cb < S; ++cb)
-                        acc += st[(size_t)((dir * S + comp) * S + cb) * A.nn_max + node] *
-                               phis[(jx + jy * npx) * S + cb];
+                        acc = fma(st[(size_t)((dir * S + comp) * S + cb) * A.nn_max + node],
+                                  phis[(jx + jy * npx) * S + cb], acc);
                     }
               }
             op[dof] = acc;
@@ -817,17 +1150,23 @@ namespace
 // -------------------------------------------------------------------------------------
 size_t slod_solve_lds_bytes(int S, int m_max, int nc_max)
 {
-  const int    R = (m_max + 15) / 16, BW = 2 * (2 * S - 1) + 1;
-  const size_t n = (size_t)m_max * (m_max + 1) + 2 * (size_t)m_max * nc_max + 2 * 16 * R +
-                   3 * (size_t)m_max * BW;
-  return n * sizeof(double);
+  // must mirror the carve-up at the top of k_solve
+  const int    R = (m_max + 15) / 16, BW = 2 * (2 * S - 1) + 1, NB = 16 * R, RBS = NB + 2;
+  const int    ldv = (m_max + 1) & ~1, ncs = (nc_max + 1) & ~1;
+  size_t       n   = (size_t)ldv * ldv + 2 * (size_t)ldv * ncs + 2 * RBS +
+             3 * (size_t)((m_max * BW + 1) & ~1);
+  size_t bytes = n * sizeof(double) + 2 * (size_t)nc_max * sizeof(int);
+  // gemm_tile over-reads Vs rows up to NB-1 (results discarded): keep them inside the block
+  bytes = bytes > ((size_t)NB * ldv + ldv) * sizeof(double) ? bytes : ((size_t)NB * ldv + ldv) * sizeof(double);
+  return (bytes + 15) & ~(size_t)15;
 }
 
 size_t slod_select_lds_bytes(int /*S*/, int nb_max, int nc_max, int nf_max)
 {
-  const size_t n = (size_t)nc_max * (nc_max + 1) + (size_t)nc_max * nc_max +
-                   (size_t)nb_max * nc_max + nf_max + 5 * (size_t)nc_max + 8;
-  return n * sizeof(double) + ((size_t)nc_max + 2) * sizeof(int);
+  // must mirror the carve-up at the top of k_select
+  const size_t bd = (size_t)nb_max * nc_max > (size_t)nf_max ? (size_t)nb_max * nc_max : (size_t)nf_max;
+  const size_t n  = (size_t)nc_max * (nc_max + 1) + (size_t)nc_max * nc_max + bd + 5 * (size_t)nc_max + 8;
+  return n * sizeof(double) + (3 * (size_t)nc_max + 4) * sizeof(int);
 }
 
 hipError_t slod_launch_assemble(int S, const SlodKernelArgs &a, int n_patches, hipStream_t st)
