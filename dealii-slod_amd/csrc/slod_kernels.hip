@@ -230,7 +230,7 @@ namespace
   {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const SlodPatchDesc d = A.desc[blockIdx.x];
-    constexpr int       W = 2 * S - 1, BW = 2 * W + 1, NB = 16 * R, RBS = NB + 2;
+    constexpr int       W = 2 * S - 1, BW = 2 * W + 1, NB = 16 * R, RBS = 2 * NB;
     const int           tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
     const int           m = d.m, L = d.L, nc = d.n_c, n = A.n_sub;
     const int           mm = A.m_max, ldv = (mm + 1) & ~1, m_even = (m + 1) & ~1;
@@ -278,50 +278,39 @@ namespace
           }
         __syncthreads();
 
-        // S_l = T_l - B_{l-1}^T V_{l-1} B_{l-1} in registers
+        // S_l = T_l - B_{l-1}^T U_{l-1} in registers, U_{l-1} = V_{l-1} B_{l-1} was left in Vs by
+        // the previous iteration
         double a[R][R];
 #pragma unroll
-        for (int rb = 0; rb < R; ++rb)
+        for (int ra = 0; ra < R; ++ra)
           {
-            const int j = tx + 16 * rb;
-            double    bj[BW];
+            const int i = ty + 16 * ra;
+            double    bi[BW];
 #pragma unroll
-            for (int f = 0; f < BW; ++f)
+            for (int e = 0; e < BW; ++e)
               {
-                const int q = j + f - W;
-                bj[f]       = (l > 0 && j < m && q >= 0 && q < m) ? Bp[q * BW + (2 * W - f)] : 0.0;
+                const int p = i + e - W;
+                bi[e]       = (l > 0 && i < m && p >= 0 && p < m && !(A.diag & 1)) ? Bp[p * BW + (2 * W - e)] : 0.0;
               }
 #pragma unroll
-            for (int ra = 0; ra < R; ++ra)
+            for (int rb = 0; rb < R; ++rb)
               {
-                const int i = ty + 16 * ra;
+                const int j = tx + 16 * rb;
                 double    v = 0.0;
                 if (i < m && j < m)
                   {
                     const int o = j - i;
                     if (o >= -W && o <= W)
                       v = Tb[i * BW + o + W];
-                    if (l > 0 && !(A.diag & 1))
+#pragma unroll
+                    for (int e = 0; e < BW; ++e)
                       {
-                        double acc = 0.0;
-#pragma unroll
-                        for (int e = 0; e < BW; ++e)
-                          {
-                            const int    p  = i + e - W;
-                            const int    pc = min(max(p, 0), m - 1);
-                            const double bi = (p >= 0 && p < m) ? Bp[pc * BW + (2 * W - e)] : 0.0;
-                            double       inner = 0.0;
-#pragma unroll
-                            for (int f = 0; f < BW; ++f)
-                              {
-                                const int qc = min(max(j + f - W, 0), m - 1);
-                                inner        = fma(Vs[pc * ldv + qc], bj[f], inner);
-                              }
-                            acc = fma(bi, inner, acc);
-                          }
-                        v -= acc;
+                        const int pc = min(max(i + e - W, 0), m - 1);
+                        v            = fma(-bi[e], Vs[pc * ldv + j], v);
                       }
                   }
+                else if (i == j && i == m && (m & 1))
+                  v = 1.0; // identity padding for the 2x2 block sweep
                 a[ra][rb] = v;
               }
           }
@@ -364,45 +353,53 @@ namespace
           }
         __syncthreads();
 
-        // symmetric Gauss-Jordan sweep: a <- -S_l^{-1}.  One barrier per pivot; the chain
-        // per step is: pivot thread rcp -> LDS publish -> barrier -> LDS read -> FMA.
-        for (int k = 0; k < ((A.diag & 4) ? 1 : m); ++k)
+        // symmetric Gauss-Jordan sweep with 2x2 block pivots: a <- -S_l^{-1}.  Rows k, k+1 are
+        // published by their owner lanes, every thread inverts the 2x2 pivot block itself
+        // (one Newton reciprocal) => ONE barrier per two pivots.  Odd m is padded with an
+        // identity row/column (set when S_l was built).
+        for (int k = 0; k < ((A.diag & 4) ? 2 : m_even); k += 2)
           {
-            const int ka = k >> 4, kt = k & 15;
-            double   *rbuf = rowbuf + (k & 1) * RBS;
-            if (ty == kt)
+            const int ka = k >> 4, kt = k & 15; // k even: k+1 has the same ka and kt+1
+            double   *row0 = rowbuf + ((k >> 1) & 1) * RBS, *row1 = row0 + NB;
+            if (ty == kt || ty == kt + 1)
               {
+                double *dst = (ty == kt) ? row0 : row1;
 #pragma unroll
                 for (int ra = 0; ra < R; ++ra)
                   if (ra == ka)
                     {
 #pragma unroll
                       for (int rb = 0; rb < R; ++rb)
-                        rbuf[tx + 16 * rb] = a[ra][rb];
-                      if (tx == kt)
-                        {
-                          const double piv = a[ra][ra];
-                          rbuf[NB]         = fast_rcp(piv);
-                          if (!(piv > 0.0) && !A.diag)
-                            atomicOr(A.status, 1);
-                        }
+                        dst[tx + 16 * rb] = a[ra][rb];
                     }
               }
             __syncthreads();
-            const double p = rbuf[NB];
-            double       ri[R], sj[R];
+            const double pa = row0[k], pb = row0[k + 1], pc = row1[k + 1];
+            const double det = fma(pa, pc, -(pb * pb));
+            if (tid == 0 && !(det > 0.0 && pa > 0.0) && !A.diag)
+              atomicOr(A.status, 1);
+            const double idet = fast_rcp(det);
+            const double P00 = pc * idet, P01 = -pb * idet, P11 = pa * idet;
+            double       ri0[R], ri1[R], s0[R], s1[R];
 #pragma unroll
             for (int ra = 0; ra < R; ++ra)
-              ri[ra] = rbuf[ty + 16 * ra];
+              {
+                ri0[ra] = row0[ty + 16 * ra];
+                ri1[ra] = row1[ty + 16 * ra];
+              }
 #pragma unroll
             for (int rb = 0; rb < R; ++rb)
-              sj[rb] = rbuf[tx + 16 * rb] * p;
+              {
+                const double rj0 = row0[tx + 16 * rb], rj1 = row1[tx + 16 * rb];
+                s0[rb]           = fma(P00, rj0, P01 * rj1);
+                s1[rb]           = fma(P01, rj0, P11 * rj1);
+              }
 #pragma unroll
             for (int ra = 0; ra < R; ++ra)
 #pragma unroll
               for (int rb = 0; rb < R; ++rb)
-                a[ra][rb] = fma(-ri[ra], sj[rb], a[ra][rb]);
-            if (ty == kt) // row k: r_j / pivot
+                a[ra][rb] = fma(-ri1[ra], s1[rb], fma(-ri0[ra], s0[rb], a[ra][rb]));
+            if (ty == kt || ty == kt + 1) // rows k, k+1: P r_j
               {
 #pragma unroll
                 for (int ra = 0; ra < R; ++ra)
@@ -410,10 +407,10 @@ namespace
                     {
 #pragma unroll
                       for (int rb = 0; rb < R; ++rb)
-                        a[ra][rb] = sj[rb];
+                        a[ra][rb] = (ty == kt) ? s0[rb] : s1[rb];
                     }
               }
-            if (tx == kt) // column k: r_i / pivot, (k,k): -1/pivot
+            if (tx == kt || tx == kt + 1) // columns k, k+1: P r_i; pivot block: -P
               {
 #pragma unroll
                 for (int rb = 0; rb < R; ++rb)
@@ -421,9 +418,15 @@ namespace
                     {
 #pragma unroll
                       for (int ra = 0; ra < R; ++ra)
-                        a[ra][rb] = ri[ra] * p;
+                        {
+                          const double t0 = fma(P00, ri0[ra], P01 * ri1[ra]);
+                          const double t1 = fma(P01, ri0[ra], P11 * ri1[ra]);
+                          a[ra][rb]       = (tx == kt) ? t0 : t1;
+                        }
                       if (ty == kt)
-                        a[rb][rb] = -p;
+                        a[rb][rb] = (tx == kt) ? -P00 : -P01;
+                      if (ty == kt + 1)
+                        a[rb][rb] = (tx == kt) ? -P01 : -P11;
                     }
               }
           }
@@ -470,6 +473,49 @@ namespace
                     }
                 }
             }
+        // U_l = V_l B_l replaces V_l in Vs (only the next line's Schur complement reads it)
+        if (l + 1 < L && !(A.diag & 1))
+          {
+            double u[R][R];
+#pragma unroll
+            for (int rb = 0; rb < R; ++rb)
+              {
+                const int j = tx + 16 * rb;
+                double    bj[BW];
+#pragma unroll
+                for (int f = 0; f < BW; ++f)
+                  {
+                    const int q = j + f - W;
+                    bj[f]       = (j < m && q >= 0 && q < m) ? Bn[q * BW + (2 * W - f)] : 0.0;
+                  }
+#pragma unroll
+                for (int ra = 0; ra < R; ++ra)
+                  {
+                    const int i   = ty + 16 * ra;
+                    double    acc = 0.0;
+                    if (i < m && j < m)
+                      {
+#pragma unroll
+                        for (int f = 0; f < BW; ++f)
+                          {
+                            const int qc = min(max(j + f - W, 0), m - 1);
+                            acc          = fma(Vs[i * ldv + qc], bj[f], acc);
+                          }
+                      }
+                    u[ra][rb] = acc;
+                  }
+              }
+            __syncthreads(); // every read of V_l (GEMM above, U tiles) is done
+#pragma unroll
+            for (int ra = 0; ra < R; ++ra)
+#pragma unroll
+              for (int rb = 0; rb < R; ++rb)
+                {
+                  const int i = ty + 16 * ra, j = tx + 16 * rb;
+                  if (i < m && j < m)
+                    Vs[i * ldv + j] = u[ra][rb];
+                }
+          }
         double *t = Bp;
         Bp        = Bn;
         Bn        = t;
@@ -1151,7 +1197,7 @@ namespace
 size_t slod_solve_lds_bytes(int S, int m_max, int nc_max)
 {
   // must mirror the carve-up at the top of k_solve
-  const int    R = (m_max + 15) / 16, BW = 2 * (2 * S - 1) + 1, NB = 16 * R, RBS = NB + 2;
+  const int    R = (m_max + 15) / 16, BW = 2 * (2 * S - 1) + 1, NB = 16 * R, RBS = 2 * NB;
   const int    ldv = (m_max + 1) & ~1, ncs = (nc_max + 1) & ~1;
   size_t       n   = (size_t)ldv * ldv + 2 * (size_t)ldv * ncs + 2 * RBS +
              3 * (size_t)((m_max * BW + 1) & ~1);
