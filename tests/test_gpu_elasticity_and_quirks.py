@@ -1,0 +1,160 @@
+"""GPU parity for the vector-valued (elasticity) path, the reference quirk switches, the
+non-2^k golden geometry and ragged / edge-case plans.  Same tolerances as test_gpu_parity."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, make_fields
+from test_gpu_parity import _check_patch, _mk, _upload
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("stabilize", [0, 1])
+@pytest.mark.parametrize("proj_quirk", [0, 1])
+def test_elasticity_small_all_patches(so, stabilize, proj_quirk):
+    """ElasticityProblem geometry (Elasticity.h): 2 components, H=1/4, n=4, l=1, (lambda,mu) random."""
+    cfg, g = _mk(so, nref=2, n_sub=4, oversampling=1, spacedim=2, stabilize=stabilize, proj_quirk=proj_quirk)
+    fields = make_fields(so, cfg, "D100")
+    _upload(g, fields)
+    ids = np.arange(g.num_patches)
+    basis, premult, offs = g.compute_basis(ids)
+    for k, pid in enumerate(ids):
+        _check_patch(so, cfg, fields, int(pid), basis, premult, int(offs[k]), "elast")
+
+
+def test_elasticity_c4_sample(so):
+    """BASELINE config C4: 2-D elasticity H=1/32, n=8, l=2 (3362 dofs, 50 candidates per full
+    patch).  The oracle needs ~0.1 s per patch, so 40 patches covering every patch shape."""
+    cfg, g = _mk(so, nref=5, n_sub=8, oversampling=2, spacedim=2, stabilize=1)
+    fields = make_fields(so, cfg, "D100")
+    _upload(g, fields)
+    shapes = {}
+    for pid in range(g.num_patches):
+        i = g.patch_layout(pid)
+        shapes.setdefault((i.mx, i.my, tuple(i.side_domain)), []).append(pid)
+    ids = sorted({v[0] for v in shapes.values()} | {v[len(v) // 2] for v in shapes.values()} | {341, 682, 1023})
+    ids = np.array(ids[:40])
+    basis, premult, offs = g.compute_basis(ids)
+    worst = 0.0
+    for k, pid in enumerate(ids):
+        e = _check_patch(so, cfg, fields, int(pid), basis, premult, int(offs[k]), "C4")
+        worst = max(worst, e[0])
+    print("C4 sample of %d patches: worst |dphi| %.3e" % (len(ids), worst))
+
+
+def test_constant_coefficient_reuse_quirk(so):
+    """quirk Q1 (LOD.cc:354-362): with constant_coefficients every full patch re-uses the FIRST
+    full patch's matrix even though the field is random."""
+    cfg, g = _mk(so, nref=3, n_sub=4, oversampling=1, stabilize=1, reuse_full=1)
+    fields = make_fields(so, cfg, "D100")
+    _upload(g, fields)
+    ids = np.arange(g.num_patches)
+    basis, premult, offs = g.compute_basis(ids)
+    for k, pid in enumerate(ids):
+        _check_patch(so, cfg, fields, int(pid), basis, premult, int(offs[k]), "Q1")
+    # full patches with the same boundary ids must be bit-identical now
+    groups = {}
+    for k in ids:
+        i = g.patch_layout(int(k))
+        if i.mx == 3 and i.my == 3:
+            groups.setdefault(tuple(i.side_domain), []).append(int(k))
+    assert len(groups[(0, 0, 0, 0)]) >= 4
+    for members in groups.values():
+        n = g.patch_layout(members[0]).n_fine
+        ref = basis[int(offs[members[0]]):int(offs[members[0]]) + n]
+        for k in members[1:]:
+            assert np.array_equal(basis[int(offs[k]):int(offs[k]) + n], ref)
+
+
+def test_solve_poisson_problem_on_patch_01_golden(so):
+    """The reference golden tests/solve_poisson_problem_on_patch_01.output through the HIP path:
+    10x10 grid (not 2^k), 7 subdivisions, overlap 3, patch of cell (1,4); the sum of the columns
+    of X = A_c^{-1} P^T solves -lap u = 1 with zero Dirichlet data (sum_k P^T[:,k] = int phi_i)."""
+    gold = np.array([float(x) for x in open(os.path.join(
+        GOLDEN, "reference", "solve_poisson_problem_on_patch_01.output")).read().split()])
+    cfg, g = _mk(so, n_cells=10, n_sub=7, oversampling=3, stabilize=0)
+    g.set_coefficient(0, np.ones(70 * 70 * 4))
+    pid = 1 + 4 * 10
+    info = g.patch_layout(pid)
+    assert (info.x0, info.y0, info.mx, info.my) == (0, 1, 5, 7)
+    u = g.patch_solution(pid).sum(axis=1)
+    out = np.zeros(71 * 71)
+    ix = np.arange(info.n_fine) % (info.nx + 1)
+    iy = np.arange(info.n_fine) // (info.nx + 1)
+    out[(info.x0 * 7 + ix) + (info.y0 * 7 + iy) * 71] = u
+    nz = gold != 0
+    assert np.array_equal(nz, out != 0)
+    assert np.max(np.abs(out[nz] - gold[nz]) / np.abs(gold[nz])) < 6e-4   # 4 printed digits
+
+
+def test_ragged_offsets_empty_and_repeated_ids(so):
+    cfg, g = _mk(so, nref=3, n_sub=4, oversampling=1, stabilize=1)
+    fields = make_fields(so, cfg, "D100")
+    _upload(g, fields)
+    # empty plan
+    b, p, o = g.compute_basis(np.zeros(0, dtype=np.uint32))
+    assert b.size == 0
+    # reversed order with gaps between patches, one id twice
+    ids = np.array([63, 0, 27, 27, 9], dtype=np.uint32)
+    sizes = [g.patch_layout(int(i)).n_fine for i in ids]
+    offs = np.cumsum([0] + [s + 7 for s in sizes[:-1]]).astype(np.uint64)
+    total = int(offs[-1]) + sizes[-1]
+    basis, premult, _ = g.compute_basis(ids, offsets=offs, total=total)
+    for k, pid in enumerate(ids):
+        _check_patch(so, cfg, fields, int(pid), basis, premult, int(offs[k]), "ragged")
+    for k in range(len(ids) - 1):   # the gaps stay untouched
+        gap = basis[int(offs[k]) + sizes[k]:int(offs[k + 1])]
+        assert np.all(gap == 0.0)
+    # id out of range
+    import slod_amd
+    with pytest.raises(slod_amd.SlodError) as e:
+        g.compute_basis(np.array([64], dtype=np.uint32))
+    assert e.value.code == -1
+
+
+def test_ensemble_of_problems(so):
+    """n_problems > 1: gid = problem*num_patches + patch_id picks the coefficient realisation."""
+    import slod_amd
+    kw = dict(nref=2, n_sub=4, oversampling=1, stabilize=1)
+    cfg = so.make_cfg(**kw)
+    g = slod_amd.Slod(n_problems=3, **kw)
+    NE = g.NE
+    fields = [so.fill_coefficient(100 + pb, 0, 1.0, 100.0, NE) for pb in range(3)]
+    for pb in range(3):
+        g.set_coefficient(0, fields[pb], problem=pb)
+    gids = np.array([2 * 16 + 5, 0 * 16 + 5, 1 * 16 + 15], dtype=np.uint32)
+    basis, premult, offs = g.compute_basis(gids)
+    for k, gid in enumerate(gids):
+        _check_patch(so, cfg, [fields[int(gid) // 16]], int(gid) % 16, basis, premult, int(offs[k]), "ens")
+
+
+def test_size_independent_properties_at_full_size(so):
+    """C2 at full size, properties that need no oracle: phi vanishes on every patch
+    boundary dof, has unit l2 norm; psi = 0 on id-0 dofs; on internal dofs psi is the (h^2/4){1,2,4}
+    weighted cell pattern P^T c / ||phi_raw|| (one value per cell, interior cell edge and interior cell
+    vertex: at most (2mx-1)(2my-1) distinct |values| per patch); two executions give bit-identical results."""
+    cfg, g = _mk(so, nref=5, n_sub=8, oversampling=2, stabilize=1)
+    fields = make_fields(so, cfg, "D1e4")
+    _upload(g, fields)
+    ids = np.arange(g.num_patches)
+    b1, p1, offs = g.compute_basis(ids)
+    b2, p2, _ = g.compute_basis(ids)
+    assert np.array_equal(b1, b2) and np.array_equal(p1, p2)
+    for k in ids[::37]:
+        info = g.patch_layout(int(k))
+        n = info.n_fine
+        phi = b1[int(offs[k]):int(offs[k]) + n].reshape(info.ny + 1, info.nx + 1)
+        psi = p1[int(offs[k]):int(offs[k]) + n].reshape(info.ny + 1, info.nx + 1)
+        assert abs(np.linalg.norm(phi) - 1.0) < 1e-13
+        assert np.all(phi[0, :] == 0) and np.all(phi[-1, :] == 0) and np.all(phi[:, 0] == 0) and np.all(phi[:, -1] == 0)
+        sd = list(info.side_domain)
+        if sd[0]:
+            assert np.all(psi[:, 0] == 0)
+        if sd[3]:
+            assert np.all(psi[-1, :] == 0)
+        inner = psi[1:-1, 1:-1]
+        scale = np.abs(inner).max()
+        distinct = np.unique(np.round(np.abs(inner) / scale, 7))
+        assert distinct.size <= (2 * info.mx - 1) * (2 * info.my - 1) + 1
