@@ -70,6 +70,12 @@ def cpu_baseline(cfg_kw, fields, n_full):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
+    try:  # a container CPU quota (cgroup v2) is the real core budget
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
     # 1 thread: the reference's execution model per rank (MPI_InitFinalize(...,1)); 128 patches
     sub = ids[::8]
     t0 = time.perf_counter()
@@ -122,7 +128,7 @@ def main():
     slod = slod_amd.Slod(n_problems=world, device=local_rank, **C2)
     NP = slod.num_patches
     total = NP * world
-    begin, end = slod_amd.partition(total, world, rank)
+    begin, end = slod_amd.partition(total, world, rank)     # LOD.cc:116-118
     gids = np.arange(begin, end, dtype=np.uint32)
     from slod_amd.synthetic import fill_coefficient
     lo, hi = (1.0, 100.0) if args.dist == "D100" else (1.0, 1.0e4)
@@ -132,11 +138,11 @@ def main():
         fields[pb] = fill_coefficient(SEED + 1000 * pb, args.dist, slod.NE)
         t = torch.from_numpy(fields[pb]).to(dev)                  # resident in HBM before timing
         slod.set_coefficient_device(0, t.data_ptr(), t.numel(), problem=pb)
+    from slod_amd import distributed as sd
     plan = slod.plan(gids)                                        # uniform stride -> all-gather slabs
     n_local = len(gids)
-    n_slab = (total + world - 1) // world                         # padded slab (ragged tail)
-    basis = torch.zeros(n_slab * plan.stride, dtype=torch.float64, device=dev)
-    premult = torch.zeros(n_slab * plan.stride, dtype=torch.float64, device=dev)
+    basis = sd.allocate_slab(total, world, plan.stride, dev)      # padded slab (ragged tail)
+    premult = sd.allocate_slab(total, world, plan.stride, dev)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
@@ -166,15 +172,13 @@ def main():
     # the exchange step (outside the metric): RCCL all-gather of the (phi,psi) slabs
     allgather_ms = None
     if world > 1:
-        gb = torch.empty(world * basis.numel(), dtype=torch.float64, device=dev)
-        gp = torch.empty(world * premult.numel(), dtype=torch.float64, device=dev)
         for _ in range(2):
-            dist.all_gather_into_tensor(gb, basis)
-            dist.all_gather_into_tensor(gp, premult)
+            gb = sd.all_gather_slabs(basis, world)
+            gp = sd.all_gather_slabs(premult, world)
         barrier()
         ta = time.perf_counter()
-        dist.all_gather_into_tensor(gb, basis)
-        dist.all_gather_into_tensor(gp, premult)
+        gb = sd.all_gather_slabs(basis, world)
+        gp = sd.all_gather_slabs(premult, world)
         barrier()
         allgather_ms = (time.perf_counter() - ta) * 1e3
         # every rank's block must land where a single-GPU run would put it
