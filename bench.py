@@ -88,7 +88,7 @@ def cpu_baseline(cfg_kw, fields, n_full):
         so.basis_many(cfg, fields, ids, offs, total, nthreads=cores)
         reps += 1
         tall = time.perf_counter() - t0
-        if tall > 4.0 or reps >= 20:
+        if tall > 6.0 or reps >= 400:
             break
     return {"value": reps * len(ids) / tall, "unit": "patches/s", "cores": cores, "kind": "port",
             "sample": "all %d patches of C2 x %d passes, OpenMP over patches (%.1f s wall); "
