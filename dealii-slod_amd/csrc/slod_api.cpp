@@ -510,7 +510,8 @@ int slod_plan_create(slod_handle *h, const uint32_t *gids, size_t n, const uint6
   // holds nb_buf rows, at least nc_max + 16 so every chunk brings new rows
   p->nb_buf = std::min(p->nb_max, std::max(96, p->nc_max + 16));
   const size_t lds_max = 160 * 1024;
-  if (slod_solve_lds_bytes(s, p->m_max, p->nc_max, 0) > lds_max ||
+  if ((slod_solve_lds_bytes(s, p->m_max, p->nc_max, 0) > lds_max &&
+       !(slod_solve_ws_tile(p->m_max) && slod_solve_ws_lds_bytes(s, p->m_max, p->nc_max) <= lds_max)) ||
       slod_select_lds_bytes(s, p->nb_buf, p->nc_max, p->nf_max) > lds_max)
     {
       delete p;
@@ -518,7 +519,11 @@ int slod_plan_create(slod_handle *h, const uint32_t *gids, size_t n, const uint6
     }
   p->nn_max    = (p->nn_max + 31) & ~31; // 256-byte aligned stencil planes
   p->st_stride = (size_t)9 * s * s * p->nn_max;
-  p->v_stride  = (size_t)p->L_max * p->m_max * p->m_max;
+  {
+    // k_solve_ws stores V lines as (8T)^2 blocks; the cooperative kernel as m_max^2
+    const int mp = std::max(p->m_max, 8 * slod_solve_ws_tile(p->m_max));
+    p->v_stride  = (size_t)p->L_max * mp * mp;
+  }
   p->x_stride  = (size_t)p->L_max * p->m_max * p->nc_max;
   const size_t per_patch = (p->st_stride + p->v_stride + p->x_stride) * sizeof(double);
   size_t       budget_mb = 24 * 1024;

@@ -63,6 +63,8 @@ hipError_t slod_launch_solve(int S, const SlodKernelArgs &a, int n_patches, hipS
 hipError_t slod_launch_select(int S, const SlodKernelArgs &a, int n_patches, int nb_max,
                               int nf_max, hipStream_t st);
 size_t     slod_solve_lds_bytes(int S, int m_max, int nc_max, int twisted);
+size_t     slod_solve_ws_lds_bytes(int S, int m_max, int nc_max);
+int        slod_solve_ws_tile(int m_max);
 size_t     slod_select_lds_bytes(int S, int nb_max, int nc_max, int nf_max);
 
 #endif
