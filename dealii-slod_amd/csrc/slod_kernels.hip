@@ -204,6 +204,16 @@ namespace
     return fma(x, e, x);
   }
 
+  // 1/sqrt(x) to ~1 ulp: v_rsq_f64 + two Newton steps (the Jacobi rotation's dependent chain
+  // otherwise carries two IEEE sqrt and three IEEE divisions, ~250 instructions)
+  __device__ __forceinline__ double fast_rsqrt(double x)
+  {
+    double y = __builtin_amdgcn_rsq(x);
+    double h = 0.5 * x;
+    y        = y * fma(-h * y, y, 1.5);
+    return y * fma(-h * y, y, 1.5);
+  }
+
   template <int R>
   __device__ __forceinline__ void gemm_tile(const double *__restrict__ Vs, int ldv,
                                             const double *__restrict__ Rb, int ncs, int m_even,
@@ -792,7 +802,7 @@ namespace
     double *Rb   = Vs + ldv * ldv;       // [ldv][ncs]  right-hand side block
     double *Zp   = Rb + ldv * ncs;       // [ldv][ncs]  Z of the previous line / X of the next
     double *rowb = Zp + ldv * ncs;       // [MP]        pivot row of the GJ wave
-    double *Tn   = rowb + MP;            // [mm][BW]    band of T_{l+1}
+    double *Tn   = rowb + 2 * MP;        // padded band of T_{l+1}
     double *Bc0  = Tn + bsz;             // [mm][BW]    coupling bands, alternating
     double *Bc1  = Bc0 + bsz;
     int    *colk = reinterpret_cast<int *>(Bc1 + bsz); // [2][nc_max]
@@ -803,7 +813,7 @@ namespace
     const int     ncg   = A.nc_max;
     const size_t  vline = (size_t)MP * MP, xline = (size_t)mm * ncg;
 
-    for (int idx = tid; idx < ldv * ldv + 2 * ldv * ncs + MP + 3 * bsz; idx += 256)
+    for (int idx = tid; idx < ldv * ldv + 2 * ldv * ncs + 2 * MP + 3 * bsz; idx += 256)
       smem[idx] = 0.0;
     __syncthreads();
     for (int c = tid; c < nc; c += 256)
@@ -822,6 +832,15 @@ namespace
             Tdst[(i + W) * BWP + oi] = coupling<S>(st, A.nn_max, npx, tr, m, line, i, 0, o);
           if (Bdst)
             Bdst[(i + W) * BWP + oi] = (line + 1 < L) ? coupling<S>(st, A.nn_max, npx, tr, m, line, i, 1, o) : 0.0;
+        }
+      // identity on the padding rows of T (the 2x2 block sweep may pivot on index m, m odd);
+      // the coupling buffers are zero there (Bc1 is used for T_0 first)
+      for (int i = m + t0; i < MP; i += nt)
+        {
+          if (Tdst)
+            Tdst[(i + W) * BWP + W] = 1.0;
+          if (Bdst)
+            Bdst[(i + W) * BWP + W] = 0.0;
         }
     };
     // prologue: T_0 goes to Bc1 (free until B_1 is loaded), T_1 to Tn, B_0 to Bc0
@@ -843,16 +862,9 @@ namespace
         // a <- S_{l+1} = Tsrc - Bl^T V_l Bl with V_l = -a, entirely in registers: the tile
         // neighbours in j come from lanes +-1, in i from lanes +-8 (needs T >= W)
         auto next_S = [&](const double *Tsrc, const double *Bl) __attribute__((always_inline)) {
-          // U = V Bl, row by row in place
-          double cB[T][BW];
-#pragma unroll
-          for (int tb = 0; tb < T; ++tb)
-#pragma unroll
-            for (int f = 0; f < BW; ++f)
-              {
-                const int q = T * gx + tb + f - W; // B_l[q][j]: band row q (padded), offset j - q
-                cB[tb][f]   = Bl ? Bl[(q + W) * BWP + (2 * W - f)] : 0.0;
-              }
+          // U = V Bl, row by row in place.  Coefficients are re-read from the (zero padded)
+          // LDS bands instead of being kept in registers: the tile alone is 2*T*T VGPRs.
+          const double *cb = Bl + (T * gx) * BWP + 2 * W; // B_l[q][j] = cb[(tb + f) * BWP - f]
 #pragma unroll
           for (int ta = 0; ta < T; ++ta)
             {
@@ -872,21 +884,13 @@ namespace
                   double acc = 0.0;
 #pragma unroll
                   for (int f = 0; f < BW; ++f)
-                    acc = fma(ext[tb + f], cB[tb][f], acc);
+                    acc = fma(ext[tb + f], cb[(tb + f) * BWP - f], acc);
                   a[ta][tb] = acc;
                 }
               __builtin_amdgcn_sched_barrier(0); // keep the shuffles of one row together (VGPR pressure)
             }
           // S = Tsrc - Bl^T U, column by column in place
-          double dB[T][BW];
-#pragma unroll
-          for (int ta = 0; ta < T; ++ta)
-#pragma unroll
-            for (int e = 0; e < BW; ++e)
-              {
-                const int p = T * gy + ta + e - W;
-                dB[ta][e]   = Bl ? Bl[(p + W) * BWP + (2 * W - e)] : 0.0;
-              }
+          const double *db = Bl + (T * gy) * BWP + 2 * W; // B_l[p][i] = db[(ta + e) * BWP - e]
 #pragma unroll
           for (int tb = 0; tb < T; ++tb)
             {
@@ -909,14 +913,17 @@ namespace
                   double         acc = Tsrc[(i + W) * BWP + (oi < (unsigned)BW ? oi : (unsigned)BW)];
 #pragma unroll
                   for (int e = 0; e < BW; ++e)
-                    acc = fma(-ext[ta + e], dB[ta][e], acc);
+                    acc = fma(-ext[ta + e], db[(ta + e) * BWP - e], acc);
                   a[ta][tb] = acc;
                 }
               __builtin_amdgcn_sched_barrier(0);
             }
         };
         // pivots [k0, k1) of the symmetric sweep a <- -S^{-1}; rows are published to rowb
-        // (wave-private: the DS queue of one wave is in order, no workgroup barrier needed)
+        // (wave-private: the DS queue of one wave is in order, no workgroup barrier needed).
+        // (A 2x2 block-pivot variant halves the LDS round trips but needs 20 more live
+        // doubles; with the 128-VGPR budget of 4 workgroups/CU it measured slower.)
+        bool bad = false;
         auto sweep = [&](int k0, int k1) __attribute__((always_inline)) {
           for (int ka = k0 / T; ka * T < k1; ++ka)
             {
@@ -936,8 +943,7 @@ namespace
                   __builtin_amdgcn_wave_barrier();
                   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                   const double piv = rowb[k];
-                  if (lane == 0 && !(piv > 0.0) && !A.diag)
-                    atomicOr(A.status, 1);
+                  bad |= !(piv > 0.0);
                   const double p = fast_rcp(piv);
                   double       ri[T], sj[T];
 #pragma unroll
@@ -1000,11 +1006,13 @@ namespace
             if (l > 0)
               __syncthreads(); // C_{l-1}
             sweep(ksplit, m);
+            if (bad && lane == 0 && !A.diag)
+              atomicOr(A.status, 1);
             __syncthreads(); // B'_l
             store_V(l);
             __syncthreads(); // A_l
             if (l + 1 < L)
-              next_S(Tn, (A.diag & 1) ? nullptr : ((l & 1) ? Bc1 : Bc0));
+              next_S(Tn, (l & 1) ? Bc1 : Bc0);
           }
         __syncthreads(); // C_{L-1}
         __syncthreads(); // end of the forward sweep
@@ -1169,12 +1177,27 @@ namespace
   // ---------------------------------------------------------------------------------
   // K3: coarse Schur block, (S)LOD selection, normalisation, premultiplication
   // ---------------------------------------------------------------------------------
+  // all-reduce inside a 16-lane row with DPP rotations (row_ror:8,4,2,1): ~4 VALU steps
+  // instead of four LDS-routed shuffles on the dependent chain of every Jacobi rotation
+  template <int CTRL>
+  __device__ __forceinline__ double dpp_rot(double v)
+  {
+    union
+    {
+      double d;
+      int    i[2];
+    } in, out;
+    in.d     = v;
+    out.i[0] = __builtin_amdgcn_mov_dpp(in.i[0], CTRL, 0xf, 0xf, false);
+    out.i[1] = __builtin_amdgcn_mov_dpp(in.i[1], CTRL, 0xf, 0xf, false);
+    return out.d;
+  }
   __device__ __forceinline__ double group16_sum(double v)
   {
-    v += __shfl_xor(v, 8, 16);
-    v += __shfl_xor(v, 4, 16);
-    v += __shfl_xor(v, 2, 16);
-    v += __shfl_xor(v, 1, 16);
+    v += dpp_rot<0x128>(v); // row_ror:8
+    v += dpp_rot<0x124>(v); // row_ror:4
+    v += dpp_rot<0x122>(v); // row_ror:2
+    v += dpp_rot<0x121>(v); // row_ror:1
     return v;
   }
 
@@ -1535,15 +1558,44 @@ namespace
                       }
                   }
               }
-            if (need_svd && !(A.diag & 512))
+            if (need_svd && !(A.diag & (512 | 4096)))
               {
-                // ---- one-sided Jacobi SVD on the nr x nn1 matrix in BD (R after the QR, BD'
-                //      itself if nb < nn1); sigma(G) = sigma^2, u_j^T g = w_j . b0
+                // ---- one-sided Jacobi SVD (the reference's singular triplets are needed).
+                // After the QR the sweeps run on L = R^T (Drmac/Veselic: much faster convergence
+                // than on R): L J = W with orthogonal columns w_j = sigma_j v_j (v_j = right
+                // singular vectors of R = those of BD'), J = left singular vectors of R, so
+                // sigma_j(G) = |w_j|^2, u_j^T g = sigma_j (J_j . c), and the reference's term
+                // v_j (u_j^T g) / sigma_j(G) = w_j (J_j . c) / |w_j|^2.  Without a QR (fewer rows
+                // than columns) the sweeps run on BD' itself: W = BD' V, term = V_j (w_j . b0)/|w_j|^2.
+                const bool tposed = did_qr && nbuf >= 2 * nn1;
+                double    *Wm     = BD;              // matrix whose columns are rotated
+                int        wr     = nr;              // its rows
+                if (tposed)
+                  {
+                    Wm = BD + (size_t)nn1 * ncm;     // rows nn1..2nn1-1 of the buffer are free now
+                    for (int idx = tid; idx < nn1 * nn1; idx += 256)
+                      {
+                        const int i = idx / nn1, j = idx - i * nn1;       // L[i][j] = R[j][i]
+                        Wm[i * ncm + j] = (j <= i) ? BD[j * ncm + cix(i)] : 0.0;
+                      }
+                    wr = nn1;
+                  }
+                auto wcol = [&](int j) { return tposed ? j : cix(j); };
                 const int nev = (nn1 + 1) & ~1;
                 for (int idx = tid; idx < nn1 * nn1; idx += 256)
                   Vj[idx] = ((idx / nn1) == (idx % nn1)) ? 1.0 : 0.0;
-                __syncthreads();
-                for (int sweep = 0; sweep < 40; ++sweep)
+                // Frobenius norm^2 (rotation invariant): columns below 1e-22 of it are numerically
+                // zero -- seven orders under the reference's 1e-15 cutoff on sigma(G) -- and are
+                // not rotated (two noise columns never pass the relative test and would keep
+                // every sweep busy on rank-deficient rim patches)
+                double fro = 0.0;
+                for (int idx = tid; idx < wr * nn1; idx += 256)
+                  {
+                    const double w = Wm[(idx / nn1) * ncm + wcol(idx % nn1)];
+                    fro            = fma(w, w, fro);
+                  }
+                const double tiny = 1e-22 * block_sum(fro);
+                for (int sweep = 0; sweep < ((A.diag & 8192) ? 3 : 40); ++sweep)
                   {
                     if (tid == 0)
                       flag[0] = 0;
@@ -1560,17 +1612,19 @@ namespace
                               }
                             else
                               {
-                                pa = (round + pr) % (nev - 1);
-                                pb = (round - pr + (nev - 1)) % (nev - 1);
+                                pa = round + pr;
+                                pa = pa >= nev - 1 ? pa - (nev - 1) : pa;
+                                pb = round - pr;
+                                pb = pb < 0 ? pb + (nev - 1) : pb;
                               }
                             if (pa >= nn1 || pb >= nn1)
                               continue;
                             const int p = pa < pb ? pa : pb, q = pa < pb ? pb : pa;
-                            const int cp = cix(p), cq = cix(q);
+                            const int cp = wcol(p), cq = wcol(q);
                             double    app = 0, aqq = 0, apq = 0;
-                            for (int r = l16; r < nr; r += 16)
+                            for (int r = l16; r < wr; r += 16)
                               {
-                                const double wp = BD[r * ncm + cp], wq = BD[r * ncm + cq];
+                                const double wp = Wm[r * ncm + cp], wq = Wm[r * ncm + cq];
                                 app = fma(wp, wp, app);
                                 aqq = fma(wq, wq, aqq);
                                 apq = fma(wp, wq, apq);
@@ -1578,17 +1632,20 @@ namespace
                             app = group16_sum(app);
                             aqq = group16_sum(aqq);
                             apq = group16_sum(apq);
-                            if (apq == 0.0 || fabs(apq) <= 1e-15 * sqrt(app * aqq))
+                            if (apq == 0.0 || apq * apq <= 1e-30 * (app * aqq) || fmin(app, aqq) <= tiny)
                               continue;
-                            const double zeta = (aqq - app) / (2.0 * apq);
-                            const double t =
-                              (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                            const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
-                            for (int r = l16; r < nr; r += 16)
+                            // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (aqq-app)/(2 apq),
+                            // written without the division by apq; c = 1/sqrt(1+t^2), s = c t
+                            const double dd = aqq - app;
+                            const double hh = fma(dd, dd, 4.0 * apq * apq);
+                            const double hy = hh * fast_rsqrt(hh); // sqrt(dd^2 + 4 apq^2)
+                            const double t  = (dd >= 0.0 ? 2.0 : -2.0) * apq * fast_rcp(fabs(dd) + hy);
+                            const double cs = fast_rsqrt(fma(t, t, 1.0)), sn = cs * t;
+                            for (int r = l16; r < wr; r += 16)
                               {
-                                const double wp = BD[r * ncm + cp], wq = BD[r * ncm + cq];
-                                BD[r * ncm + cp] = cs * wp - sn * wq;
-                                BD[r * ncm + cq] = sn * wp + cs * wq;
+                                const double wp = Wm[r * ncm + cp], wq = Wm[r * ncm + cq];
+                                Wm[r * ncm + cp] = cs * wp - sn * wq;
+                                Wm[r * ncm + cq] = sn * wp + cs * wq;
                               }
                             for (int r = l16; r < nn1; r += 16)
                               {
@@ -1606,62 +1663,73 @@ namespace
                     if (!any)
                       break;
                   }
+                // sig_j = sigma_j(G); utg_j = coefficient of the j-th term's vector
                 for (int j = tid; j < nn1; j += 256)
                   {
-                    const int cj = cix(j);
+                    const int cj = wcol(j);
                     double    ss = 0, wb = 0;
-                    for (int r = 0; r < nr; ++r)
+                    for (int r = 0; r < wr; ++r)
                       {
-                        const double w = BD[r * ncm + cj];
+                        const double w = Wm[r * ncm + cj];
                         ss             = fma(w, w, ss);
-                        wb             = fma(w, BD[r * ncm + dsel], wb);
+                        if (!tposed)
+                          wb = fma(w, BD[r * ncm + dsel], wb);           // w_j . b0
                       }
+                    if (tposed)
+                      for (int i = 0; i < nn1; ++i)
+                        wb = fma(Vj[i * nn1 + j], BD[i * ncm + dsel], wb); // J_j . c
                     sig[j] = ss;
                     utg[j] = wb;
                   }
                 __syncthreads();
+                // term vectors: V_j (no QR) or w_j (after the QR); element a2 of term j
+                auto tvec = [&](int a2, int j) { return tposed ? Wm[a2 * ncm + j] : Vj[a2 * nn1 + j]; };
                 if (tid == 0)
                   {
-                    // descending sigma, pseudo-inverse cutoff (LOD.cc:667), d = -G^+ g, then the
-                    // 0.5-loop (LOD.cc:703-725)
+                    // descending sigma, pseudo-inverse cutoff (LOD.cc:667)
                     for (int j = 0; j < nn1; ++j)
                       ord[j] = j;
                     for (int a2 = 1; a2 < nn1; ++a2)
                       {
                         const int o = ord[a2];
-                        int       b = a2 - 1;
-                        while (b >= 0 && sig[ord[b]] < sig[o])
+                        int       b2 = a2 - 1;
+                        while (b2 >= 0 && sig[ord[b2]] < sig[o])
                           {
-                            ord[b + 1] = ord[b];
-                            --b;
+                            ord[b2 + 1] = ord[b2];
+                            --b2;
                           }
-                        ord[b + 1] = o;
+                        ord[b2 + 1] = o;
                       }
-                    const double s0  = sig[ord[0]];
-                    double      *del = rowk;
-                    for (int a2 = 0; a2 < nn1; ++a2)
-                      del[a2] = 0.0;
-                    for (int r = 0; r < nn1; ++r)
-                      {
-                        const int j = ord[r];
-                        utg[j]      = (sig[j] > 1e-15 * s0) ? utg[j] / sig[j] : 0.0;
-                        for (int a2 = 0; a2 < nn1; ++a2)
-                          del[a2] -= Vj[a2 * nn1 + j] * utg[j];
-                      }
-                    for (int r = nn1 - 1; r >= 0; --r)
-                      {
-                        double dinf = 0.0;
-                        for (int a2 = 0; a2 < nn1; ++a2)
-                          dinf = fmax(dinf, fabs(del[a2]));
-                        if (dinf < 0.5)
-                          break;
-                        const int j = ord[r];
-                        for (int a2 = 0; a2 < nn1; ++a2)
-                          del[a2] += Vj[a2 * nn1 + j] * utg[j];
-                      }
+                    const double s0 = sig[ord[0]];
                     for (int j = 0; j < nn1; ++j)
-                      gam[cix(j)] = del[j];
+                      utg[j] = (sig[j] > 1e-15 * s0) ? utg[j] / sig[j] : 0.0;
                   }
+                __syncthreads();
+                // d = -G^+ g (LOD.cc:669-671), one thread per component
+                double del = 0.0;
+                if (tid < nn1)
+                  for (int j = 0; j < nn1; ++j)
+                    del = fma(-tvec(tid, j), utg[j], del);
+                // the 0.5-loop (LOD.cc:703-725): put the smallest remaining triplet back while
+                // ||d||_inf >= 0.5 (the test precedes every removal)
+                for (int r = nn1 - 1; r >= 0; --r)
+                  {
+                    double dmax = (tid < nn1) ? fabs(del) : 0.0;
+                    for (int off = 32; off > 0; off >>= 1)
+                      dmax = fmax(dmax, __shfl_xor(dmax, off, 64));
+                    __syncthreads();
+                    if (lane == 0)
+                      red[4 + wave] = dmax;
+                    __syncthreads();
+                    const double dinf = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+                    if (dinf < 0.5)
+                      break;
+                    const int j = ord[r];
+                    if (tid < nn1)
+                      del = fma(tvec(tid, j), utg[j], del);
+                  }
+                if (tid < nn1)
+                  gam[cix(tid)] = del;
               }
           }
         __syncthreads();
@@ -1800,7 +1868,7 @@ size_t slod_solve_ws_lds_bytes(int S, int m_max, int nc_max)
   const int    T = slod_solve_ws_tile(m_max), W = 2 * S - 1, BW = 2 * W + 1, MP = 8 * T;
   const int    ldv = MP + 2, ncs = (nc_max + 1) & ~1, bsz = ((MP + 2 * W) * (BW + 1) + 1) & ~1;
   (void)m_max;
-  const size_t n = (size_t)ldv * ldv + 2 * (size_t)ldv * ncs + MP + 3 * (size_t)bsz;
+  const size_t n = (size_t)ldv * ldv + 2 * (size_t)ldv * ncs + 2 * MP + 3 * (size_t)bsz;
   return ((n * sizeof(double) + 2 * (size_t)nc_max * sizeof(int)) + 15) & ~(size_t)15;
 }
 
