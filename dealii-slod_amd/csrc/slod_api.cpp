@@ -46,7 +46,7 @@ struct slod_plan
   int                        nb_buf = 0; // rows of k_select's boundary-trace buffer
   size_t                     stride = 0, out_size = 0;
   size_t                     chunk = 0;
-  double                    *ws_st = nullptr, *ws_v = nullptr, *ws_x = nullptr;
+  double                    *ws_st = nullptr, *ws_v = nullptr, *ws_x = nullptr, *ws_m = nullptr;
   size_t                     st_stride = 0, v_stride = 0, x_stride = 0;
   int32_t                   *d_status = nullptr;
   std::vector<hipEvent_t>    ev; // [depth][n_chunks][4]
@@ -241,6 +241,8 @@ namespace
     a.xs        = p->ws_x;
     a.x_stride  = p->x_stride;
     a.nc_max    = p->nc_max;
+    a.ms        = p->ws_m;
+    a.m_fused   = 0; // set by slod_launch_solve when the wave-specialised kernel runs
     a.basis     = d_basis;
     a.premult   = d_premult;
     a.status    = p->d_status;
@@ -535,6 +537,7 @@ int slod_plan_create(slod_handle *h, const uint32_t *gids, size_t n, const uint6
   ok       = ok && hipMalloc((void **)&p->ws_st, p->chunk * p->st_stride * sizeof(double)) == hipSuccess;
   ok       = ok && hipMalloc((void **)&p->ws_v, p->chunk * p->v_stride * sizeof(double)) == hipSuccess;
   ok       = ok && hipMalloc((void **)&p->ws_x, p->chunk * p->x_stride * sizeof(double)) == hipSuccess;
+  ok       = ok && hipMalloc((void **)&p->ws_m, p->chunk * (size_t)p->nc_max * p->nc_max * sizeof(double)) == hipSuccess;
   ok       = ok && hipMalloc((void **)&p->d_status, sizeof(int32_t)) == hipSuccess;
   ok = ok && hipMemcpy(p->d_desc, p->desc.data(), n * sizeof(SlodPatchDesc), hipMemcpyHostToDevice) ==
                hipSuccess;
@@ -568,6 +571,8 @@ void slod_plan_destroy(slod_plan *p)
     (void)hipFree(p->ws_v);
   if (p->ws_x)
     (void)hipFree(p->ws_x);
+  if (p->ws_m)
+    (void)hipFree(p->ws_m);
   if (p->d_status)
     (void)hipFree(p->d_status);
   delete p;
@@ -597,7 +602,7 @@ int slod_plan_execute(slod_plan *p, double *d_basis, double *d_premult, void *hi
   for (size_t first = 0; first < p->n && e == hipSuccess; first += p->chunk, ++ci)
     {
       const int            cnt = (int)std::min(p->chunk, p->n - first);
-      const SlodKernelArgs a   = make_args(p, first, d_basis, d_premult);
+      SlodKernelArgs       a   = make_args(p, first, d_basis, d_premult);
       hipEvent_t          *ev  = &p->ev[4 * ((p->n_exec % (size_t)p->depth) * p->n_chunks + ci)];
       e = hipEventRecord(ev[0], st);
       if (e == hipSuccess)
@@ -605,7 +610,7 @@ int slod_plan_execute(slod_plan *p, double *d_basis, double *d_premult, void *hi
       if (e == hipSuccess)
         e = hipEventRecord(ev[1], st);
       if (e == hipSuccess)
-        e = slod_launch_solve(s, a, cnt, st);
+        e = slod_launch_solve(s, a, cnt, st); // sets a.m_fused
       if (e == hipSuccess)
         e = hipEventRecord(ev[2], st);
       if (e == hipSuccess)

@@ -51,6 +51,8 @@ struct SlodKernelArgs
   double *xs;
   size_t  x_stride;
   int32_t nc_max;
+  double *ms;       // per patch M = P^T A^-1 P / H^2 accumulated by k_solve_ws (nc_max^2 doubles)
+  int32_t m_fused;  // 1: k_select reads M from ms instead of recomputing it from X
   // outputs
   double  *basis;
   double  *premult;
@@ -59,7 +61,7 @@ struct SlodKernelArgs
 
 // launchers (slod_kernels.hip)
 hipError_t slod_launch_assemble(int S, const SlodKernelArgs &a, int n_patches, hipStream_t st);
-hipError_t slod_launch_solve(int S, const SlodKernelArgs &a, int n_patches, hipStream_t st);
+hipError_t slod_launch_solve(int S, SlodKernelArgs &a, int n_patches, hipStream_t st);
 hipError_t slod_launch_select(int S, const SlodKernelArgs &a, int n_patches, int nb_max,
                               int nf_max, hipStream_t st);
 size_t     slod_solve_lds_bytes(int S, int m_max, int nc_max, int twisted);

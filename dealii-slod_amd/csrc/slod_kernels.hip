@@ -989,7 +989,7 @@ namespace
                 vl[i * MP + j]  = v;
               }
         };
-        const int ksplit = m / 3; // pivots done before barrier C (the helpers build R meanwhile)
+        const int ksplit = m / 3, ksplit2 = (2 * m) / 3; // barriers C, D are taken inside the sweep
         // S_0 = T_0 (held in Bc1 during the prologue)
 #pragma unroll
         for (int ta = 0; ta < T; ++ta)
@@ -1005,7 +1005,10 @@ namespace
             sweep(0, ksplit);
             if (l > 0)
               __syncthreads(); // C_{l-1}
-            sweep(ksplit, m);
+            sweep(ksplit, ksplit2);
+            if (l > 0 && A.m_fused)
+              __syncthreads(); // D_{l-1}
+            sweep(ksplit2, m);
             if (bad && lane == 0 && !A.diag)
               atomicOr(A.status, 1);
             __syncthreads(); // B'_l
@@ -1015,6 +1018,8 @@ namespace
               next_S(Tn, (l & 1) ? Bc1 : Bc0);
           }
         __syncthreads(); // C_{L-1}
+        if (A.m_fused)
+          __syncthreads(); // D_{L-1}
         __syncthreads(); // end of the forward sweep
       }
     else
@@ -1077,6 +1082,30 @@ namespace
                 }
             }
         };
+        // M = P^T A^-1 P / H^2 = sum_l R_l^T Z_l (block LDL^T identity, LOD.cc:548-551): every
+        // helper thread owns up to MA entries; accumulated while the GJ wave sweeps
+        constexpr int MA = 4; // nc^2 <= 768 (nc <= 27); larger patches let k_select compute M from X
+        double        macc[MA];
+        int           mab[MA]; // a + 64 * b, or -1
+#pragma unroll
+        for (int q = 0; q < MA; ++q)
+          {
+            const int idx = hid + 192 * q;
+            macc[q]       = 0.0;
+            mab[q]        = (A.m_fused && idx < nc * nc) ? (idx / nc) + 64 * (idx % nc) : -1;
+          }
+        auto accumulate_M = [&]() __attribute__((always_inline)) {
+#pragma unroll
+          for (int q = 0; q < MA; ++q)
+            if (mab[q] >= 0)
+              {
+                const int ca = mab[q] & 63, cb = mab[q] >> 6;
+                double    acc = macc[q];
+                for (int i = 0; i < m; ++i)
+                  acc = fma(Rb[i * ncs + ca], Zp[i * ncs + cb], acc);
+                macc[q] = acc;
+              }
+        };
         for (int l = 0; l < L; ++l)
           {
             if (l > 0)
@@ -1084,6 +1113,11 @@ namespace
                 build_R(l - 1);
                 __syncthreads(); // C_{l-1}: R_{l-1} complete, every read of Z_{l-2} is done
                 gemm_Z(l - 1);
+                if (A.m_fused)
+                  {
+                    __syncthreads(); // D_{l-1}: Z_{l-1} complete
+                    accumulate_M();
+                  }
                 // bands the GJ wave needs after A_l: T_{l+1}, B_l
                 if (l + 1 < L && !(A.diag & 32))
                   load_bands(l + 1, Tn, nullptr, hid, 192);
@@ -1096,6 +1130,16 @@ namespace
         build_R(L - 1);
         __syncthreads(); // C_{L-1}
         gemm_Z(L - 1);
+        if (A.m_fused)
+          {
+            __syncthreads(); // D_{L-1}
+            accumulate_M();
+            double *mg = A.ms + (size_t)blockIdx.x * A.nc_max * A.nc_max;
+#pragma unroll
+            for (int q = 0; q < MA; ++q)
+              if (mab[q] >= 0)
+                mg[(mab[q] & 63) * nc + (mab[q] >> 6)] = macc[q] * A.invH2;
+          }
         __syncthreads(); // end of the forward sweep
       }
 
@@ -1307,7 +1351,13 @@ namespace
     // ---- M = P^T X / H^dim (LOD.cc:548-551).  X rows come from the global workspace: the
     //      inner loop has no control dependence (clamped address, zero weight on the patch
     //      boundary where X = 0) so its n+1 loads are in flight together.
-    for (int idx = tid; idx < ((A.diag & 64) ? 0 : nc * nc); idx += 256)
+    if (A.m_fused)
+      {
+        const double *mg = A.ms + (size_t)blockIdx.x * A.nc_max * A.nc_max;
+        for (int idx = tid; idx < nc * nc; idx += 256)
+          Ms[(idx / nc) * ldm + (idx % nc)] = mg[idx];
+      }
+    for (int idx = tid; idx < ((A.diag & 64) || A.m_fused ? 0 : nc * nc); idx += 256)
       {
         const int a = idx / nc, b = idx - a * nc;
         const int kx = colk[a], ky = colk[ncm + a];
@@ -1459,53 +1509,94 @@ namespace
                       break;       // cannot happen: nbuf > nn1
                     continue;
                   }
-                // ---- Householder QR of the rows x [BD' | b0] block, in place
+                // ---- Householder QR of the rows x [BD' | b0] block, in place.  One barrier per
+                // reflector: the 16-lane group that updates the NEXT pivot column also
+                // accumulates its norm below the diagonal (sigma of the next step).
                 did_qr = true;
+                {
+                  double part = 0.0;
+                  for (int r = tid; r < rows; r += 256)
+                    {
+                      const double x = BD[r * ncm + cix(0)];
+                      part           = fma(x, x, part);
+                    }
+                  const double s00 = block_sum(part);
+                  if (tid == 0)
+                    sig[0] = s00;
+                  __syncthreads();
+                }
                 for (int k = 0; k < nn1; ++k)
                   {
-                    const int ck = cix(k);
-                    double    part = 0.0;
-                    for (int r = k + tid; r < rows; r += 256)
-                      {
-                        const double x = BD[r * ncm + ck];
-                        part           = fma(x, x, part);
-                      }
-                    const double sigma = block_sum(part);
+                    const int    ck    = cix(k);
+                    const double sigma = sig[k & 1];
                     if (!(sigma > 0.0))
                       {
+                        // zero column (rank deficient): no reflector; the next column's norm
                         if (r0 >= nb)
-                          singular = true; // zero column: rank deficient, replay via the SVD
+                          singular = true; // replayed through the SVD
+                        if (k + 1 < nn1)
+                          {
+                            double part = 0.0;
+                            for (int r = k + 1 + tid; r < rows; r += 256)
+                              {
+                                const double x = BD[r * ncm + cix(k + 1)];
+                                part           = fma(x, x, part);
+                              }
+                            const double sn = block_sum(part);
+                            if (tid == 0)
+                              sig[(k + 1) & 1] = sn;
+                          }
+                        __syncthreads();
                         continue;
                       }
                     const double x0    = BD[k * ncm + ck];
-                    const double alpha = (x0 >= 0.0) ? -sqrt(sigma) : sqrt(sigma);
+                    const double sq    = sigma * fast_rsqrt(sigma);
+                    const double alpha = (x0 >= 0.0) ? -sq : sq;
                     const double v0    = x0 - alpha;
-                    const double beta  = 1.0 / (sigma - alpha * x0); // 2 / v^T v
-                    __syncthreads();
+                    const double beta  = fast_rcp(sigma - alpha * x0); // 2 / v^T v
                     // apply H = I - beta v v^T to the trailing columns and to b0
                     for (int t = grp; t < nn1 - k; t += 16)
                       {
                         const int cj = (t == nn1 - k - 1) ? dsel : cix(k + 1 + t);
-                        double    s  = 0.0;
+                        double    sd = 0.0;
                         for (int r = k + l16; r < rows; r += 16)
                           {
                             const double vr = (r == k) ? v0 : BD[r * ncm + ck];
-                            s               = fma(vr, BD[r * ncm + cj], s);
+                            sd              = fma(vr, BD[r * ncm + cj], sd);
                           }
-                        s = group16_sum(s) * beta;
+                        sd = group16_sum(sd) * beta;
+                        double nxt = 0.0;
                         for (int r = k + l16; r < rows; r += 16)
                           {
-                            const double vr   = (r == k) ? v0 : BD[r * ncm + ck];
-                            BD[r * ncm + cj] = fma(-s, vr, BD[r * ncm + cj]);
+                            const double vr = (r == k) ? v0 : BD[r * ncm + ck];
+                            const double nv = fma(-sd, vr, BD[r * ncm + cj]);
+                            BD[r * ncm + cj] = nv;
+                            if (r > k)
+                              nxt = fma(nv, nv, nxt);
+                          }
+                        if (t == 0 && k + 1 < nn1) // cj is the next pivot column
+                          {
+                            nxt = group16_sum(nxt);
+                            if (l16 == 0)
+                              sig[(k + 1) & 1] = nxt;
                           }
                       }
                     __syncthreads();
                     if (tid == 0)
-                      BD[k * ncm + ck] = alpha;
-                    for (int r = k + 1 + tid; r < rows; r += 256)
-                      BD[r * ncm + ck] = 0.0;
-                    __syncthreads();
+                      BD[k * ncm + ck] = alpha; // R_kk (after the barrier: x0 was read from here)
                   }
+                // clear the strict lower triangle of the R block (dead reflector storage): the
+                // next chunk's QR and the SVD fallback read it as part of the matrix
+                for (int idx = tid; idx < nn1 * nn1; idx += 256)
+                  {
+                    const int r = idx / nn1, j = idx - r * nn1;
+                    if (r > j)
+                      BD[r * ncm + cix(j)] = 0.0;
+                  }
+                for (int r = nn1 + tid; r < rows; r += 256)
+                  for (int j = 0; j < nn1; ++j)
+                    BD[r * ncm + cix(j)] = 0.0;
+                __syncthreads();
                 filled = nn1;
                 nr     = nn1;
               }
@@ -1927,15 +2018,22 @@ static hipError_t launch_ws_S(const SlodKernelArgs &a, int n_patches, size_t lds
     }
 }
 
-hipError_t slod_launch_solve(int S, const SlodKernelArgs &a, int n_patches, hipStream_t st)
+hipError_t slod_launch_solve(int S, SlodKernelArgs &a, int n_patches, hipStream_t st)
 {
+  a.m_fused = 0;
   // default: wave-specialised forward sweep (k_solve_ws); SLOD_SOLVE=coop selects the
   // cooperative 256/512-thread kernel (k_solve)
   {
     const char  *sel = getenv("SLOD_SOLVE");
     const size_t lds = slod_solve_ws_tile(a.m_max) ? slod_solve_ws_lds_bytes(S, a.m_max, a.nc_max) : 0;
     if (!(sel && !strcmp(sel, "coop")) && lds && lds <= 160 * 1024 && slod_solve_ws_tile(a.m_max) >= 2 * S - 1)
-      return S == 1 ? launch_ws_S<1>(a, n_patches, lds, st) : launch_ws_S<2>(a, n_patches, lds, st);
+      {
+        // fusing M = sum_l R_l^T Z_l into the helper waves saves k_select's re-read of X but
+        // costs a fourth barrier per line; measured neutral on C2, so opt-in (SLOD_FUSE_M=1)
+        const char *fm = getenv("SLOD_FUSE_M");
+        a.m_fused      = (fm && atoi(fm) && a.nc_max * a.nc_max <= 192 * 4) ? 1 : 0;
+        return S == 1 ? launch_ws_S<1>(a, n_patches, lds, st) : launch_ws_S<2>(a, n_patches, lds, st);
+      }
   }
   // twisted (two chains, 512 threads) when the GPU is not full anyway: it halves the
   // dependent chain per patch; one chain per patch otherwise (same work, more patches
