@@ -857,6 +857,9 @@ namespace
     if (wave == 0)
       {
         // ===== the Gauss-Jordan wave =====
+        // it is the critical path of the workgroup and shares its SIMD with helper waves of
+        // other workgroups: win the issue arbitration
+        __builtin_amdgcn_s_setprio(3);
         const int gy = lane >> 3, gx = lane & 7;
         double    a[T][T];
         // a <- S_{l+1} = Tsrc - Bl^T V_l Bl with V_l = -a, entirely in registers: the tile
@@ -1017,6 +1020,7 @@ namespace
             if (l + 1 < L)
               next_S(Tn, (l & 1) ? Bc1 : Bc0);
           }
+        __builtin_amdgcn_s_setprio(0);
         __syncthreads(); // C_{L-1}
         if (A.m_fused)
           __syncthreads(); // D_{L-1}
@@ -1106,10 +1110,47 @@ namespace
                 macc[q] = acc;
               }
         };
+        // The stencil entries of the next bands come from global memory (L2/HBM latency):
+        // they are fetched into registers at the top of an iteration and written to LDS after
+        // the GEMM, so the latency is off the path to barrier B'.
+        constexpr int NBV = (MP * BW + 191) / 192;
+        double        tband[NBV], bband[NBV];
+        auto fetch_bands = [&](int l) __attribute__((always_inline)) {
+#pragma unroll
+          for (int q = 0; q < NBV; ++q)
+            {
+              const int idx = hid + 192 * q;
+              const int i = idx / BW, o = idx - i * BW - W;
+              const bool in = idx < m * BW && !(A.diag & 32);
+              tband[q] = (in && l + 1 < L) ? coupling<S>(st, A.nn_max, npx, tr, m, l + 1, i, 0, o) : 0.0;
+              bband[q] = (in && l + 1 < L) ? coupling<S>(st, A.nn_max, npx, tr, m, l, i, 1, o) : 0.0;
+            }
+        };
+        auto store_bands = [&](int l) __attribute__((always_inline)) {
+          double *Bdst = (l & 1) ? Bc1 : Bc0;
+#pragma unroll
+          for (int q = 0; q < NBV; ++q)
+            {
+              const int idx = hid + 192 * q;
+              const int i = idx / BW, oi = idx - i * BW;
+              if (idx < m * BW)
+                {
+                  if (l + 1 < L)
+                    Tn[(i + W) * BWP + oi] = tband[q];
+                  Bdst[(i + W) * BWP + oi] = bband[q];
+                }
+            }
+          for (int i = m + hid; i < MP; i += 192) // padding rows: identity in T, zero in B
+            {
+              Tn[(i + W) * BWP + W]   = 1.0;
+              Bdst[(i + W) * BWP + W] = 0.0;
+            }
+        };
         for (int l = 0; l < L; ++l)
           {
             if (l > 0)
               {
+                fetch_bands(l);
                 build_R(l - 1);
                 __syncthreads(); // C_{l-1}: R_{l-1} complete, every read of Z_{l-2} is done
                 gemm_Z(l - 1);
@@ -1118,11 +1159,8 @@ namespace
                     __syncthreads(); // D_{l-1}: Z_{l-1} complete
                     accumulate_M();
                   }
-                // bands the GJ wave needs after A_l: T_{l+1}, B_l
-                if (l + 1 < L && !(A.diag & 32))
-                  load_bands(l + 1, Tn, nullptr, hid, 192);
-                if (!(A.diag & 32))
-                  load_bands(l, nullptr, (l & 1) ? Bc1 : Bc0, hid, 192);
+                // bands the GJ wave needs after A_l: T_{l+1}, B_l (fetched before the GEMM)
+                store_bands(l);
               }
             __syncthreads(); // B'_l
             __syncthreads(); // A_l
