@@ -743,41 +743,31 @@ namespace
   // whole m x m matrix in registers (8x8 lane grid x TxT contiguous tile, m <= 8T), publishes
   // pivot row k to a wave-private LDS line (in-order DS queue of one wave: no barrier) and
   // runs all m steps alone, while the other three waves of the workgroup build the
-  // right-hand-side block and do the GEMM Z_l = V_l R_l of the line just inverted.  Three
+  // right-hand-side block and do the GEMM Z_l = V_l R_l of the line just inverted on the fp64
+  // matrix pipe (v_mfma_f64_16x16x4_f64), which leaves the VALU issue slots to the GJ waves.  Three
   // workgroup barriers per line (not per pivot):
   //     A_l : V_l is in LDS (Vs), Z_{l-1} is in Zp, bands of the next stage are loaded
   //     C_l : helpers have built R_l                     (GJ wave: after its first steps)
   //     B_l : helpers are done with Vs (Z_l is in Zp)    (GJ wave: after its last step)
   // then the GJ wave overwrites Vs with V_{l+1}.  The backward substitution uses all 4 waves.
   // ---------------------------------------------------------------------------------
-  constexpr int kRH = 3; // GEMM register tile: kRH rows x 2 columns per thread
-
   __host__ __device__ constexpr int ws_min_waves(int T) { return T <= 5 ? 4 : (T <= 7 ? 2 : 1); }
 
-  // acc[a][c] = sum_k Vs[i0+a][k] * Rb[k][col0+c]
-  __device__ __forceinline__ void gemm_rows(const double *__restrict__ Vs, int ldv,
-                                            const double *__restrict__ Rb, int ncs, int m_even, int i0,
-                                            int col0, double (&acc)[kRH][2])
+  // Z tile (16 x 16) = Vs[16 ti .., :] * Rb[:, 16 tj ..] on the fp64 matrix pipe
+  // (v_mfma_f64_16x16x4_f64: lane l feeds A[l&15][l>>4], B[l>>4][l&15]; D[(l>>4)+4r][l&15], r<4).
+  // Two 8-byte LDS reads per 1024 FMAs instead of 80 bytes per 12 FMAs of the VALU tile, and
+  // no VALU issue slots: the helper waves stop competing with the Gauss-Jordan waves.
+  typedef double double4_t __attribute__((ext_vector_type(4)));
+  __device__ __forceinline__ double4_t gemm_mfma_tile(const double *__restrict__ Vs, int ldv,
+                                                      const double *__restrict__ Rb, int ncs, int k4,
+                                                      int ti, int tj, int lane)
   {
-#pragma unroll
-    for (int a = 0; a < kRH; ++a)
-      acc[a][0] = acc[a][1] = 0.0;
-    const double *rp = Rb + col0;
-    const double *vp = Vs + i0 * ldv;
-    for (int k = 0; k < m_even; k += 2)
-      {
-        const double2 r0 = *reinterpret_cast<const double2 *>(rp + k * ncs);
-        const double2 r1 = *reinterpret_cast<const double2 *>(rp + (k + 1) * ncs);
-#pragma unroll
-        for (int a = 0; a < kRH; ++a)
-          {
-            const double2 v = *reinterpret_cast<const double2 *>(vp + a * ldv + k);
-            acc[a][0]       = fma(v.x, r0.x, acc[a][0]);
-            acc[a][1]       = fma(v.x, r0.y, acc[a][1]);
-            acc[a][0]       = fma(v.y, r1.x, acc[a][0]);
-            acc[a][1]       = fma(v.y, r1.y, acc[a][1]);
-          }
-      }
+    double4_t     acc = {0.0, 0.0, 0.0, 0.0};
+    const double *ap  = Vs + (16 * ti + (lane & 15)) * ldv + (lane >> 4);
+    const double *bp  = Rb + (lane >> 4) * ncs + 16 * tj + (lane & 15);
+    for (int k = 0; k < k4; k += 4)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[k], bp[k * ncs], acc, 0, 0, 0);
+    return acc;
   }
 
   template <int T, int S>
@@ -789,8 +779,8 @@ namespace
     constexpr int       BWP = BW + 1, BROWS = MP + 2 * W; // zero-padded bands: no range predicates
     const int           tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int           m = d.m, L = d.L, nc = d.n_c, n = A.n_sub;
-    const int           mm = A.m_max, ldv = MP + 2, m_even = (m + 1) & ~1;
-    const int           ncs = (A.nc_max + 1) & ~1, npairs = ncs >> 1;
+    const int           mm = A.m_max, ldv = MP + 2;
+    const int           ncs = (A.nc_max + 1) & ~1;
     const bool          tr  = (d.flags & SLOD_F_TRANSPOSED) != 0;
     const int           npx = d.nx + 1;
     constexpr int       bsz = (BROWS * BWP + 1) & ~1;
@@ -1031,8 +1021,6 @@ namespace
         // ===== the three helper waves =====
         const int hid = tid - 64; // 0..191
         const int hr = hid >> 5, hc = hid & 31; // RHS build: 6 rows x 32 columns per pass
-        const int gpr = 192 / npairs;           // GEMM: row groups of kRH rows x column pairs
-        const int gr = hid / npairs, gc = hid - gr * npairs;
         // R_l = F_l - B_{l-1}^T Z_{l-1}; F = rows of P^T (LOD.cc:478-495)
         auto build_R = [&](int l) __attribute__((always_inline)) {
           const double *Bprev = (l & 1) ? Bc0 : Bc1; // coupling l-1 -> l
@@ -1065,24 +1053,26 @@ namespace
                 }
             }
         };
-        // Z_l = V_l R_l -> Zp, workspace
+        // Z_l = V_l R_l -> Zp, workspace; 16x16 output tiles dealt to the three helper waves
+        const int k4 = (m + 3) & ~3, tiles_i = (m + 15) >> 4, tiles_j = (nc + 15) >> 4;
         auto gemm_Z = [&](int l) __attribute__((always_inline)) {
-          if (gr < gpr && !(A.diag & 8))
+          if (A.diag & 8)
+            return;
+          double *xl = xg + (size_t)l * xline;
+          for (int t = wave - 1; t < tiles_i * tiles_j; t += 3)
             {
-              double *xl = xg + (size_t)l * xline;
-              for (int i0 = gr * kRH; i0 < m; i0 += gpr * kRH)
+              const int       ti = t / tiles_j, tj = t - ti * tiles_j;
+              const double4_t acc = gemm_mfma_tile(Vs, ldv, Rb, ncs, k4, ti, tj, lane);
+              const int       col = 16 * tj + (lane & 15);
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
                 {
-                  double acc[kRH][2];
-                  gemm_rows(Vs, ldv, Rb, ncs, m_even, i0, 2 * gc, acc);
-#pragma unroll
-                  for (int ta = 0; ta < kRH; ++ta)
-#pragma unroll
-                    for (int c = 0; c < 2; ++c)
-                      if (i0 + ta < m && 2 * gc + c < nc)
-                        {
-                          Zp[(i0 + ta) * ncs + 2 * gc + c]  = acc[ta][c];
-                          xl[(i0 + ta) * ncg + 2 * gc + c] = acc[ta][c];
-                        }
+                  const int row = 16 * ti + (lane >> 4) + 4 * r;
+                  if (row < m && col < nc)
+                    {
+                      Zp[row * ncs + col] = acc[r];
+                      xl[row * ncg + col] = acc[r];
+                    }
                 }
             }
         };
@@ -1193,8 +1183,6 @@ namespace
           vpre[q]       = (idx < m * m) ? vl[(idx / m) * MP + (idx % m)] : 0.0;
         }
     };
-    const int gprb = 256 / npairs;
-    const int grb = tid / npairs, gcb = tid - grb * npairs;
     if (L >= 2 && !(A.diag & 16))
       prefetch_V(L - 2);
     for (int l = (A.diag & 16) ? -1 : L - 2; l >= 0; --l)
@@ -1226,32 +1214,35 @@ namespace
               Rb[i * ncs + r] = v;
             }
         __syncthreads();
-        // X_l = Z_l - V_l Y
-        if (grb < gprb)
-          {
-            double *xl = xg + (size_t)l * xline;
-            for (int i0 = grb * kRH; i0 < m; i0 += gprb * kRH)
-              {
-                double zl[kRH][2];
+        // X_l = Z_l - V_l Y; 16x16 output tiles dealt to the four waves
+        {
+          double   *xl = xg + (size_t)l * xline;
+          const int k4b = (m + 3) & ~3, tib = (m + 15) >> 4, tjb = (nc + 15) >> 4;
+          for (int t = wave; t < tib * tjb; t += 4)
+            {
+              const int ti = t / tjb, tj = t - ti * tjb;
+              const int col = 16 * tj + (lane & 15);
+              double    zl[4];
 #pragma unroll
-                for (int ta = 0; ta < kRH; ++ta)
+              for (int r = 0; r < 4; ++r)
+                {
+                  const int row = 16 * ti + (lane >> 4) + 4 * r;
+                  zl[r]         = (row < m && col < nc) ? xl[row * ncg + col] : 0.0;
+                }
+              const double4_t acc = gemm_mfma_tile(Vs, ldv, Rb, ncs, k4b, ti, tj, lane);
 #pragma unroll
-                  for (int c = 0; c < 2; ++c)
-                    zl[ta][c] = (i0 + ta < m && 2 * gcb + c < nc) ? xl[(i0 + ta) * ncg + 2 * gcb + c] : 0.0;
-                double acc[kRH][2];
-                gemm_rows(Vs, ldv, Rb, ncs, m_even, i0, 2 * gcb, acc);
-#pragma unroll
-                for (int ta = 0; ta < kRH; ++ta)
-#pragma unroll
-                  for (int c = 0; c < 2; ++c)
-                    if (i0 + ta < m && 2 * gcb + c < nc)
-                      {
-                        const double x = zl[ta][c] - acc[ta][c];
-                        xl[(i0 + ta) * ncg + 2 * gcb + c] = x;
-                        Zp[(i0 + ta) * ncs + 2 * gcb + c]  = x;
-                      }
-              }
-          }
+              for (int r = 0; r < 4; ++r)
+                {
+                  const int row = 16 * ti + (lane >> 4) + 4 * r;
+                  if (row < m && col < nc)
+                    {
+                      const double x     = zl[r] - acc[r];
+                      xl[row * ncg + col] = x;
+                      Zp[row * ncs + col] = x;
+                    }
+                }
+            }
+        }
         __syncthreads();
       }
   }
