@@ -1005,9 +1005,10 @@ namespace
             if (bad && lane == 0 && !A.diag)
               atomicOr(A.status, 1);
             __syncthreads(); // B'_l
-            store_V(l);
+            if (!(A.diag & 32768))
+              store_V(l);
             __syncthreads(); // A_l
-            if (l + 1 < L)
+            if (l + 1 < L && !(A.diag & 16384))
               next_S(Tn, (l & 1) ? Bc1 : Bc0);
           }
         __builtin_amdgcn_s_setprio(0);
