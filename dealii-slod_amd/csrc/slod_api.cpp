@@ -513,7 +513,8 @@ int slod_plan_create(slod_handle *h, const uint32_t *gids, size_t n, const uint6
   p->nb_buf = std::min(p->nb_max, std::max(96, p->nc_max + 16));
   const size_t lds_max = 160 * 1024;
   if ((slod_solve_lds_bytes(s, p->m_max, p->nc_max, 0) > lds_max &&
-       !(slod_solve_ws_tile(p->m_max) && slod_solve_ws_lds_bytes(s, p->m_max, p->nc_max) <= lds_max)) ||
+       !(slod_solve_ws_tile(p->m_max) && (slod_solve_ws_lds_bytes(s, p->m_max, p->nc_max) <= lds_max ||
+                                          slod_solve_tw_lds_bytes(s, p->m_max, p->nc_max) <= lds_max))) ||
       slod_select_lds_bytes(s, p->nb_buf, p->nc_max, p->nf_max) > lds_max)
     {
       delete p;

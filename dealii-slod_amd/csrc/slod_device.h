@@ -66,6 +66,7 @@ hipError_t slod_launch_select(int S, const SlodKernelArgs &a, int n_patches, int
                               int nf_max, hipStream_t st);
 size_t     slod_solve_lds_bytes(int S, int m_max, int nc_max, int twisted);
 size_t     slod_solve_ws_lds_bytes(int S, int m_max, int nc_max);
+size_t     slod_solve_tw_lds_bytes(int S, int m_max, int nc_max);
 int        slod_solve_ws_tile(int m_max);
 size_t     slod_select_lds_bytes(int S, int nb_max, int nc_max, int nf_max);
 

@@ -158,3 +158,34 @@ def test_size_independent_properties_at_full_size(so):
         scale = np.abs(inner).max()
         distinct = np.unique(np.round(np.abs(inner) / scale, 7))
         assert distinct.size <= (2 * info.mx - 1) * (2 * info.my - 1) + 1
+
+
+@pytest.mark.parametrize("mode", ["tw", "ws", "coop"])
+@pytest.mark.parametrize("spacedim", [1, 2])
+def test_all_solver_kernels(so, mode, spacedim, monkeypatch):
+    """The three patch-solve kernels (twisted wave-specialised = default, wave-specialised,
+    cooperative) must all meet the parity bar; SLOD_SOLVE selects one at launch time."""
+    monkeypatch.setenv("SLOD_SOLVE", mode)
+    kw = dict(nref=3, n_sub=4, oversampling=1, stabilize=1) if spacedim == 1 else \
+        dict(nref=2, n_sub=4, oversampling=1, spacedim=2, stabilize=1)
+    cfg, g = _mk(so, **kw)
+    fields = make_fields(so, cfg, "D100")
+    _upload(g, fields)
+    ids = np.arange(g.num_patches)
+    basis, premult, offs = g.compute_basis(ids)
+    for k, pid in enumerate(ids):
+        _check_patch(so, cfg, fields, int(pid), basis, premult, int(offs[k]), mode)
+
+
+@pytest.mark.parametrize("kw", [dict(nref=1, n_sub=2, oversampling=1), dict(nref=2, n_sub=3, oversampling=2),
+                                dict(nref=3, n_sub=2, oversampling=1), dict(nref=2, n_sub=5, oversampling=1),
+                                dict(nref=3, n_sub=6, oversampling=1)])
+def test_odd_and_tiny_shapes(so, kw):
+    """Very small patches (1-3 interior lines), odd n_sub, patches covering the whole domain."""
+    cfg, g = _mk(so, stabilize=1, **kw)
+    fields = make_fields(so, cfg, "D100")
+    _upload(g, fields)
+    ids = np.arange(g.num_patches)
+    basis, premult, offs = g.compute_basis(ids)
+    for k, pid in enumerate(ids):
+        _check_patch(so, cfg, fields, int(pid), basis, premult, int(offs[k]), "shape")
