@@ -1273,15 +1273,18 @@ namespace
     const int           mm = A.m_max, ncs = (A.nc_max + 1) & ~1, ncg = A.nc_max;
     const bool          tr  = (d.flags & SLOD_F_TRANSPOSED) != 0;
     const int           npx = d.nx + 1;
-    const int           chsz = MP * ncs + MP + 4 * bsz; // doubles per chain
+    const int           chsz = MP * ncs + MP + 6 * bsz; // doubles per chain
 
     double *cb   = smem + chain * chsz;
     double *Rb   = cb;               // [MP][ncs]  RHS block / Y of the chain
     double *rowb = Rb + MP * ncs;    // [MP]       pivot row of the chain's GJ wave
-    double *Tn0  = rowb + MP;        // padded bands, double buffered by step parity
+    double *Tf   = rowb + MP;        // padded bands: T of the chain's first line,
+    double *Tn0  = Tf + bsz;         //   T bands of the steps (by step parity),
     double *Tn1  = Tn0 + bsz;
-    double *Bc0  = Tn1 + bsz;
+    double *Bc0  = Tn1 + bsz;        //   coupling bands of the steps (by step mod 3)
     double *Bc1  = Bc0 + bsz;
+    double *Bc2  = Bc1 + bsz;
+    auto    Bbuf = [&](double *base, int stp) { return base + ((stp + 3) % 3) * bsz; };
     double *ocb  = smem + (1 - chain) * chsz; // the other chain's block
     int    *colk = reinterpret_cast<int *>(smem + 2 * chsz); // [2][nc_max]
 
@@ -1318,13 +1321,22 @@ namespace
             Bdst[(i + W) * BWP + oi] = coupling<S>(st, A.nn_max, npx, tr, m, line, i, dl, o);
         }
     };
-    // prologue (each chain's two waves = 128 threads): T of the first line, and what the GJ wave
-    // needs after A_0: T of the second line (zero if that is the meeting line of chain 1), B first->second
+    // Band schedule: right after the sweep of step t the chain's GJ wave needs the bands of
+    // "step t": T of line(t+1) (zero for chain 1's meeting line, whose T is added by chain 0) in
+    // the T buffer of parity t, and the coupling line(t) -> line(t+1) in the B buffer t mod 3.
+    // They are written one step ahead: steps 0 and 1 here, step t+1 by the helper during step t
+    // (mod 3: the helper still reads the coupling of step t-2 for its RHS block in step t).
+    auto put_step = [&](int stp, int t0, int nt) __attribute__((always_inline)) {
+      if (stp >= nmy)
+        return;
+      put_bands(line_of(chain, stp + 1), (stp & 1) ? Tn1 : Tn0, !(chain == 1 && stp + 1 == nmy), nullptr, t0, nt);
+      put_bands(line_of(chain, stp), nullptr, true, Bbuf(Bc0, stp), t0, nt);
+    };
     {
       const int t0 = (wave >> 1) * 64 + lane;
-      put_bands(line_of(chain, 0), Tn0, true, Bc0, t0, 128);
-      if (nmy > 0)
-        put_bands(line_of(chain, 1), Tn1, !(chain == 1 && nmy == 1), nullptr, t0, 128);
+      put_bands(line_of(chain, 0), Tf, true, nullptr, t0, 128);
+      put_step(0, t0, 128);
+      put_step(1, t0, 128);
     }
     __syncthreads();
 
@@ -1458,7 +1470,7 @@ namespace
             {
               const int      i = T * gy + ta, j = T * gx + tb;
               const unsigned oi = (unsigned)(j - i + W);
-              const double   v  = Tn0[(i + W) * BWP + (oi < (unsigned)BW ? oi : (unsigned)BW)];
+              const double   v  = Tf[(i + W) * BWP + (oi < (unsigned)BW ? oi : (unsigned)BW)];
               a[ta][tb]         = (chain == 1 && nmy == 0) ? 0.0 : v;
             }
         for (int t = 0; t < nstp; ++t)
@@ -1467,11 +1479,14 @@ namespace
             if (active)
               {
                 sweep();
-                store_tile(vg + (size_t)line_of(chain, t) * vline, -1.0);
+                if (!(A.diag & 32768))
+                  store_tile(vg + (size_t)line_of(chain, t) * vline, -1.0);
+                // Schur complement of the next line (the meeting line after the last step), in
+                // registers: overlaps the drain of the V stores before the barrier
+                if (!(A.diag & 16384))
+                  next_S((t & 1) ? Tn1 : Tn0, Bbuf(Bc0, t));
               }
-            __syncthreads(); // A_t
-            if (active) // Schur complement of the next line (the meeting line after the last step)
-              next_S((t & 1) ? Tn0 : Tn1, (t & 1) ? Bc1 : Bc0);
+            __syncthreads(); // A_t: V of step t is in the workspace, bands of step t+1 are in LDS
           }
         // the meeting line: a0 = T_mid - W_0, a1 = -W_1
         if (chain == 1)
@@ -1593,27 +1608,21 @@ namespace
                 av[kk] = an[kk];
             }
         };
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         for (int t = 0; t < nstp; ++t)
           {
             if (t > 0 && t - 1 < nmy)
               {
-                // line of step t-1: its V became visible at A_{t-1}
+                // RHS block and Z of line(t-1): its V became visible at A_{t-1}; the coupling
+                // line(t-2) -> line(t-1) is the B band of step t-2
                 const int line = line_of(chain, t - 1);
-                build_R(line, (t & 1) ? Bc1 : Bc0 /* B of step t-2: line(t-2) -> line(t-1) */,
-                        t > 1 ? xg + (size_t)line_of(chain, t - 2) * xline : nullptr, true, false);
+                build_R(line, Bbuf(Bc0, t - 2), t > 1 ? xg + (size_t)line_of(chain, t - 2) * xline : nullptr, true,
+                        false);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 gemm_Z(line);
               }
-            if (t < nmy && t > 0)
-              {
-                // bands the GJ wave needs after A_t: T of line(t+1) (zero for chain 1's meeting
-                // line) and B line(t) -> line(t+1)
-                const bool to_mid = (t + 1 == nmy);
-                put_bands(line_of(chain, t + 1), (t & 1) ? Tn0 : Tn1, !(chain == 1 && to_mid), nullptr, lane, 64);
-                put_bands(line_of(chain, t), nullptr, true, (t & 1) ? Bc1 : Bc0, lane, 64);
-              }
+            if (t > 0 && !(A.diag & 32))
+              put_step(t + 1, lane, 64); // bands the GJ wave needs after its next sweep
             __syncthreads(); // A_t
           }
         // R/Z of the last step (the shorter chain of an even L already did its last line in the loop)
@@ -1621,7 +1630,7 @@ namespace
           {
             const int t = nstp;
             const int line = line_of(chain, t - 1);
-            build_R(line, (t & 1) ? Bc1 : Bc0, t > 1 ? xg + (size_t)line_of(chain, t - 2) * xline : nullptr, true, false);
+            build_R(line, Bbuf(Bc0, t - 2), t > 1 ? xg + (size_t)line_of(chain, t - 2) * xline : nullptr, true, false);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             gemm_Z(line);
@@ -1631,9 +1640,9 @@ namespace
         if (chain == 0)
           {
             // R_mid = F_mid - B^T Z(mid-1) - B'^T Z(mid+1); the bands are the last B of each chain
-            const double *B0 = ((n0 - 1) & 1) ? Bc1 : Bc0;
-            const double *ob = ocb + MP * ncs + MP + 2 * bsz; // other chain's Bc0
-            const double *B1 = ((n1 - 1) & 1) ? ob + bsz : ob;
+            const double *B0 = Bbuf(Bc0, n0 - 1);
+            double       *ob = ocb + MP * ncs + MP + 3 * bsz; // other chain's Bc0
+            const double *B1 = Bbuf(ob, n1 - 1);
             build_R(mid, B0, n0 > 0 ? xg + (size_t)(mid - 1) * xline : nullptr, true, false);
             __builtin_amdgcn_wave_barrier();
             if (n1 > 0)
@@ -2570,7 +2579,7 @@ size_t slod_solve_tw_lds_bytes(int S, int m_max, int nc_max)
   const int    T = slod_solve_ws_tile(m_max), W = 2 * S - 1, BW = 2 * W + 1, MP = 8 * T;
   const int    ncs = (nc_max + 1) & ~1, bsz = ((MP + 2 * W) * (BW + 1) + 1) & ~1;
   (void)m_max;
-  const size_t chsz = (size_t)MP * ncs + MP + 4 * (size_t)bsz;
+  const size_t chsz = (size_t)MP * ncs + MP + 6 * (size_t)bsz;
   return ((2 * chsz * sizeof(double) + 2 * (size_t)nc_max * sizeof(int)) + 15) & ~(size_t)15;
 }
 
