@@ -59,9 +59,12 @@ struct SlodKernelArgs
   int32_t *status;
 };
 
-// launchers (slod_kernels.hip)
+// launchers (slod_assemble.hip, slod_solve_{tw,ws,coop}.hip, slod_select.hip)
 hipError_t slod_launch_assemble(int S, const SlodKernelArgs &a, int n_patches, hipStream_t st);
-hipError_t slod_launch_solve(int S, SlodKernelArgs &a, int n_patches, hipStream_t st);
+hipError_t slod_launch_solve(int S, SlodKernelArgs &a, int n_patches, hipStream_t st); // slod_dispatch.cpp
+hipError_t slod_launch_solve_tw(int S, const SlodKernelArgs &a, int n_patches, size_t lds, hipStream_t st);
+hipError_t slod_launch_solve_ws(int S, const SlodKernelArgs &a, int n_patches, size_t lds, hipStream_t st);
+hipError_t slod_launch_solve_coop(int S, int twisted, const SlodKernelArgs &a, int n_patches, hipStream_t st);
 hipError_t slod_launch_select(int S, const SlodKernelArgs &a, int n_patches, int nb_max,
                               int nf_max, hipStream_t st);
 size_t     slod_solve_lds_bytes(int S, int m_max, int nc_max, int twisted);

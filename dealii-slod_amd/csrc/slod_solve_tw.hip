@@ -1,0 +1,591 @@
+// k_solve_tw: twisted + wave-specialised patch solve (default).
+#include "slod_common.hip.h"
+
+namespace
+{
+  // ---------------------------------------------------------------------------------
+  // K2 (twisted + wave-specialised).  Two chains per patch: chain 0 eliminates lines
+  // 0..mid-1 downwards, chain 1 lines L-1..mid+1 upwards; they meet at line mid.  Wave c
+  // (c = 0,1) is the Gauss-Jordan wave of chain c (k_solve_ws's register scheme), wave 2+c
+  // its helper (RHS block, Z = V R on the fp64 MFMA pipe, band fetches).  V and Z/X live only
+  // in the global workspace (L2): the helpers feed the MFMA A operand straight from there, so
+  // LDS holds just the RHS block, the pivot row and the stencil bands of each chain (26 KB at
+  // C2) and four workgroups stay resident per CU while the dependent chain per patch is halved.
+  // One workgroup barrier per line pair: A_t = "V of step t is in the workspace, the bands of
+  // step t+1 are in LDS".
+  // ---------------------------------------------------------------------------------
+  template <int T, int S>
+  __global__ __launch_bounds__(256, ws_min_waves(T)) void k_solve_tw(const SlodKernelArgs A)
+  {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const SlodPatchDesc d = A.desc[blockIdx.x];
+    constexpr int       W = 2 * S - 1, BW = 2 * W + 1, MP = 8 * T;
+    constexpr int       BWP = BW + 1, BROWS = MP + 2 * W, bsz = (BROWS * BWP + 1) & ~1;
+    const int           tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int           chain = wave & 1;
+    const bool          is_gj = wave < 2;
+    const int           m = d.m, L = d.L, nc = d.n_c, n = A.n_sub;
+    const int           mm = A.m_max, ncs = (A.nc_max + 1) & ~1, ncg = A.nc_max;
+    const bool          tr  = (d.flags & SLOD_F_TRANSPOSED) != 0;
+    const int           npx = d.nx + 1;
+    const int           chsz = MP * ncs + MP + 6 * bsz; // doubles per chain
+
+    double *cb   = smem + chain * chsz;
+    double *Rb   = cb;               // [MP][ncs]  RHS block / Y of the chain
+    double *rowb = Rb + MP * ncs;    // [MP]       pivot row of the chain's GJ wave
+    double *Tf   = rowb + MP;        // padded bands: T of the chain's first line,
+    double *Tn0  = Tf + bsz;         //   T bands of the steps (by step parity),
+    double *Tn1  = Tn0 + bsz;
+    double *Bc0  = Tn1 + bsz;        //   coupling bands of the steps (by step mod 3)
+    double *Bc1  = Bc0 + bsz;
+    double *Bc2  = Bc1 + bsz;
+    auto    Bbuf = [&](double *base, int stp) { return base + ((stp + 3) % 3) * bsz; };
+    double *ocb  = smem + (1 - chain) * chsz; // the other chain's block
+    int    *colk = reinterpret_cast<int *>(smem + 2 * chsz); // [2][nc_max]
+
+    const double *st    = A.st + (size_t)blockIdx.x * A.st_stride;
+    double       *vg    = A.vinv + (size_t)blockIdx.x * A.v_stride;
+    double       *xg    = A.xs + (size_t)blockIdx.x * A.x_stride;
+    const size_t  vline = (size_t)MP * MP, xline = (size_t)mm * ncg;
+
+    const int mid = L / 2;
+    const int n0 = mid, n1 = L - 1 - mid, nstp = n0 > n1 ? n0 : n1;
+    const int nmy = chain == 0 ? n0 : n1; // lines of this chain
+    const int dl  = chain == 0 ? 1 : -1;
+    auto      line_of = [&](int c, int t) { return c == 0 ? t : L - 1 - t; }; // t == n_c gives mid
+
+    for (int idx = tid; idx < 2 * chsz; idx += 256)
+      smem[idx] = 0.0;
+    for (int c = tid; c < nc; c += 256)
+      {
+        int kx, ky;
+        cell_of_col(d, c / S, kx, ky);
+        colk[c]            = kx;
+        colk[A.nc_max + c] = ky;
+      }
+    __syncthreads();
+    // write the (zero padded) bands of `line`: T (within the line; zero band if !with_T) and the
+    // coupling line -> line + dl of this chain; t0/nt = caller's thread slice
+    auto put_bands = [&](int line, double *Tdst, bool with_T, double *Bdst, int t0, int nt) __attribute__((always_inline)) {
+      for (int idx = t0; idx < m * BW; idx += nt)
+        {
+          const int i = idx / BW, oi = idx - i * BW, o = oi - W;
+          if (Tdst)
+            Tdst[(i + W) * BWP + oi] = with_T ? coupling<S>(st, A.nn_max, npx, tr, m, line, i, 0, o) : 0.0;
+          if (Bdst)
+            Bdst[(i + W) * BWP + oi] = coupling<S>(st, A.nn_max, npx, tr, m, line, i, dl, o);
+        }
+    };
+    // Band schedule: right after the sweep of step t the chain's GJ wave needs the bands of
+    // "step t": T of line(t+1) (zero for chain 1's meeting line, whose T is added by chain 0) in
+    // the T buffer of parity t, and the coupling line(t) -> line(t+1) in the B buffer t mod 3.
+    // They are written one step ahead: steps 0 and 1 here, step t+1 by the helper during step t
+    // (mod 3: the helper still reads the coupling of step t-2 for its RHS block in step t).
+    auto put_step = [&](int stp, int t0, int nt) __attribute__((always_inline)) {
+      if (stp >= nmy)
+        return;
+      put_bands(line_of(chain, stp + 1), (stp & 1) ? Tn1 : Tn0, !(chain == 1 && stp + 1 == nmy), nullptr, t0, nt);
+      put_bands(line_of(chain, stp), nullptr, true, Bbuf(Bc0, stp), t0, nt);
+    };
+    {
+      const int t0 = (wave >> 1) * 64 + lane;
+      put_bands(line_of(chain, 0), Tf, true, nullptr, t0, 128);
+      put_step(0, t0, 128);
+      put_step(1, t0, 128);
+    }
+    __syncthreads();
+
+    // ------------------------------ forward elimination ---------------------------
+    if (is_gj)
+      {
+        __builtin_amdgcn_s_setprio(3);
+        const int gy = lane >> 3, gx = lane & 7;
+        double    a[T][T];
+        auto next_S = [&](const double *Tsrc, const double *Bl) __attribute__((always_inline)) {
+          const double *cbp = Bl + (T * gx) * BWP + 2 * W;
+#pragma unroll
+          for (int ta = 0; ta < T; ++ta)
+            {
+              double ext[T + 2 * W];
+#pragma unroll
+              for (int w = 0; w < W; ++w)
+                {
+                  ext[w]         = -__shfl(a[ta][T - W + w], lane - 1, 64);
+                  ext[W + T + w] = -__shfl(a[ta][w], lane + 1, 64);
+                }
+#pragma unroll
+              for (int tb = 0; tb < T; ++tb)
+                ext[W + tb] = -a[ta][tb];
+#pragma unroll
+              for (int tb = 0; tb < T; ++tb)
+                {
+                  double acc = 0.0;
+#pragma unroll
+                  for (int f = 0; f < BW; ++f)
+                    acc = fma(ext[tb + f], cbp[(tb + f) * BWP - f], acc);
+                  a[ta][tb] = acc;
+                }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          const double *dbp = Bl + (T * gy) * BWP + 2 * W;
+#pragma unroll
+          for (int tb = 0; tb < T; ++tb)
+            {
+              const int j = T * gx + tb;
+              double    ext[T + 2 * W];
+#pragma unroll
+              for (int w = 0; w < W; ++w)
+                {
+                  ext[w]         = __shfl(a[T - W + w][tb], lane - 8, 64);
+                  ext[W + T + w] = __shfl(a[w][tb], lane + 8, 64);
+                }
+#pragma unroll
+              for (int ta = 0; ta < T; ++ta)
+                ext[W + ta] = a[ta][tb];
+#pragma unroll
+              for (int ta = 0; ta < T; ++ta)
+                {
+                  const int      i  = T * gy + ta;
+                  const unsigned oi = (unsigned)(j - i + W);
+                  double         acc = Tsrc[(i + W) * BWP + (oi < (unsigned)BW ? oi : (unsigned)BW)];
+#pragma unroll
+                  for (int e = 0; e < BW; ++e)
+                    acc = fma(-ext[ta + e], dbp[(ta + e) * BWP - e], acc);
+                  a[ta][tb] = acc;
+                }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        bool bad = false;
+        auto sweep = [&]() __attribute__((always_inline)) {
+          for (int ka = 0; ka * T < m; ++ka)
+            {
+#pragma unroll
+              for (int a0 = 0; a0 < T; ++a0)
+                {
+                  const int k = T * ka + a0;
+                  if (k >= m || ((A.diag & 4) && k > 0)) // wave-uniform
+                    continue;
+                  if (gy == ka)
+                    {
+#pragma unroll
+                      for (int tb = 0; tb < T; ++tb)
+                        rowb[T * gx + tb] = a[a0][tb];
+                    }
+                  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                  __builtin_amdgcn_wave_barrier();
+                  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                  const double piv = rowb[k];
+                  bad |= !(piv > 0.0);
+                  const double p = fast_rcp(piv);
+                  double       ri[T], sj[T];
+#pragma unroll
+                  for (int ta = 0; ta < T; ++ta)
+                    ri[ta] = rowb[T * gy + ta];
+#pragma unroll
+                  for (int tb = 0; tb < T; ++tb)
+                    sj[tb] = rowb[T * gx + tb] * p;
+                  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                  for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+                    for (int tb = 0; tb < T; ++tb)
+                      a[ta][tb] = fma(-ri[ta], sj[tb], a[ta][tb]);
+                  if (gy == ka)
+                    {
+#pragma unroll
+                      for (int tb = 0; tb < T; ++tb)
+                        a[a0][tb] = sj[tb];
+                    }
+                  if (gx == ka)
+                    {
+#pragma unroll
+                      for (int ta = 0; ta < T; ++ta)
+                        a[ta][a0] = ri[ta] * p;
+                      if (gy == ka)
+                        a[a0][a0] = -p;
+                    }
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        // tile <-> global [MP][MP] block (V lines, and the meeting-line contribution of chain 1)
+        auto store_tile = [&](double *dst, double sign) __attribute__((always_inline)) {
+#pragma unroll
+          for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < T; ++tb)
+              dst[(T * gy + ta) * MP + T * gx + tb] = sign * a[ta][tb];
+        };
+        // a = T of the chain's first line (chain 1 without lines contributes nothing)
+#pragma unroll
+        for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+          for (int tb = 0; tb < T; ++tb)
+            {
+              const int      i = T * gy + ta, j = T * gx + tb;
+              const unsigned oi = (unsigned)(j - i + W);
+              const double   v  = Tf[(i + W) * BWP + (oi < (unsigned)BW ? oi : (unsigned)BW)];
+              a[ta][tb]         = (chain == 1 && nmy == 0) ? 0.0 : v;
+            }
+        for (int t = 0; t < nstp; ++t)
+          {
+            const bool active = t < nmy;
+            if (active)
+              {
+                sweep();
+                if (!(A.diag & 32768))
+                  store_tile(vg + (size_t)line_of(chain, t) * vline, -1.0);
+                // Schur complement of the next line (the meeting line after the last step), in
+                // registers: overlaps the drain of the V stores before the barrier
+                if (!(A.diag & 16384))
+                  next_S((t & 1) ? Tn1 : Tn0, Bbuf(Bc0, t));
+              }
+            __syncthreads(); // A_t: V of step t is in the workspace, bands of step t+1 are in LDS
+          }
+        // the meeting line: a0 = T_mid - W_0, a1 = -W_1
+        if (chain == 1)
+          store_tile(vg + (size_t)mid * vline, 1.0);
+        __syncthreads(); // M1: chain 1's contribution is in the workspace
+        if (chain == 0)
+          {
+            const double *w1 = vg + (size_t)mid * vline;
+#pragma unroll
+            for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+              for (int tb = 0; tb < T; ++tb)
+                a[ta][tb] += w1[(T * gy + ta) * MP + T * gx + tb];
+            sweep();
+            store_tile(vg + (size_t)mid * vline, -1.0);
+          }
+        if (bad && lane == 0 && !A.diag)
+          atomicOr(A.status, 1);
+        __builtin_amdgcn_s_setprio(0);
+        __syncthreads(); // M2: V_mid is in the workspace
+        __syncthreads(); // M3: X_mid is in the workspace
+      }
+    else
+      {
+        // ===== helper wave of the chain: one wave, so its own phases need no barrier =====
+        // R = (with_F ? F_line : 0) - Bprev^T Z(prev line), Z from the workspace
+        // Each lane owns column r = lane&31 (+32 ...) and one half of the rows; it walks down its
+        // rows with a sliding window of Z(prev)[p][r], p = i-W..i+W: one coalesced workspace load
+        // per row instead of 2W+1 gathers, and the loads do not depend on the arithmetic.
+        auto build_R = [&](int line, const double *Bprev, const double *zprev, bool with_F, bool add) __attribute__((always_inline)) {
+          if (A.diag & 2)
+            return;
+          const int half = lane >> 5, i_lo = half ? (m + 1) / 2 : 0, i_hi = half ? m : (m + 1) / 2;
+          for (int r = lane & 31; r < nc; r += 32)
+            {
+              const int kxn = colk[r] * n, kyn = colk[A.nc_max + r] * n;
+              double    win[BW];
+#pragma unroll
+              for (int e = 0; e < BW; ++e)
+                {
+                  const int p = i_lo + e - W;
+                  win[e]      = (zprev && p >= 0 && p < m) ? zprev[p * ncg + r] : 0.0;
+                }
+              for (int i = i_lo; i < i_hi; ++i)
+                {
+                  const int pn = i + 1 + W; // row entering the window for the next i
+                  const double znext = (zprev && pn < m) ? zprev[pn * ncg + r] : 0.0;
+                  double       v     = add ? Rb[i * ncs + r] : 0.0;
+                  if (with_F)
+                    {
+                      const int pos = i / S, comp = i - pos * S;
+                      const int ix = tr ? line + 1 : pos + 1, iy = tr ? pos + 1 : line + 1;
+                      const int jx = ix - kxn, jy = iy - kyn;
+                      if (jx >= 0 && jx <= n && jy >= 0 && jy <= n)
+                        {
+                          if (S == 1)
+                            v += A.scale * (((jx == 0 || jx == n) ? 1.0 : 2.0) * ((jy == 0 || jy == n) ? 1.0 : 2.0));
+                          else
+                            v += A.scale * pt_weight<S>(d, n, A.quirk, ix, iy, comp, r);
+                        }
+                    }
+#pragma unroll
+                  for (int e = 0; e < BW; ++e) // B[p][i], p = i+e-W (zero padded band rows)
+                    v = fma(-Bprev[(i + e) * BWP + (2 * W - e)], win[e], v);
+                  Rb[i * ncs + r] = v;
+#pragma unroll
+                  for (int e = 0; e + 1 < BW; ++e)
+                    win[e] = win[e + 1];
+                  win[BW - 1] = znext;
+                }
+            }
+        };
+        const int tiles_i = (m + 15) >> 4, tiles_j = (nc + 15) >> 4;
+        // Z(line) = V(line) Rb -> workspace; A operand straight from the workspace (rows clamped)
+        auto gemm_Z = [&](int line) __attribute__((always_inline)) {
+          if (A.diag & 8)
+            return;
+          const double *vl = vg + (size_t)line * vline;
+          double       *xl = xg + (size_t)line * xline;
+          // one row tile of A (16 x MP of V, from the workspace) feeds all column tiles; the
+          // next row tile is fetched while the MFMAs of the current one run
+          double av[MP / 4], an[MP / 4];
+          auto   load_A = [&](int ti, double (&dst)[MP / 4]) __attribute__((always_inline)) {
+            const double *ap = vl + min(16 * ti + (lane & 15), MP - 1) * MP + (lane >> 4);
+#pragma unroll
+            for (int kk = 0; kk < MP / 4; ++kk)
+              dst[kk] = ap[4 * kk];
+          };
+          load_A(0, av);
+          for (int ti = 0; ti < tiles_i; ++ti)
+            {
+              if (ti + 1 < tiles_i)
+                load_A(ti + 1, an);
+              for (int tj = 0; tj < tiles_j; tj += 2)
+                {
+                  // two independent accumulators (column tiles tj, tj+1) back to back
+                  double4_t     acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+                  const double *bp  = Rb + (lane >> 4) * ncs + 16 * tj + (lane & 15);
+                  const bool    two = tj + 1 < tiles_j;
+#pragma unroll
+                  for (int kk = 0; kk < MP / 4; ++kk)
+                    {
+                      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bp[4 * kk * ncs], acc0, 0, 0, 0);
+                      if (two)
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bp[4 * kk * ncs + 16], acc1, 0, 0, 0);
+                    }
+#pragma unroll
+                  for (int r = 0; r < 4; ++r)
+                    {
+                      const int row = 16 * ti + (lane >> 4) + 4 * r, col = 16 * tj + (lane & 15);
+                      if (row < m && col < nc)
+                        xl[row * ncg + col] = acc0[r];
+                      if (two && row < m && col + 16 < nc)
+                        xl[row * ncg + col + 16] = acc1[r];
+                    }
+                }
+#pragma unroll
+              for (int kk = 0; kk < MP / 4; ++kk)
+                av[kk] = an[kk];
+            }
+        };
+        for (int t = 0; t < nstp; ++t)
+          {
+            if (t > 0 && t - 1 < nmy)
+              {
+                // RHS block and Z of line(t-1): its V became visible at A_{t-1}; the coupling
+                // line(t-2) -> line(t-1) is the B band of step t-2
+                const int line = line_of(chain, t - 1);
+                build_R(line, Bbuf(Bc0, t - 2), t > 1 ? xg + (size_t)line_of(chain, t - 2) * xline : nullptr, true,
+                        false);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                gemm_Z(line);
+              }
+            if (t > 0 && !(A.diag & 32))
+              put_step(t + 1, lane, 64); // bands the GJ wave needs after its next sweep
+            __syncthreads(); // A_t
+          }
+        // R/Z of the last step (the shorter chain of an even L already did its last line in the loop)
+        if (nmy == nstp && nmy > 0)
+          {
+            const int t = nstp;
+            const int line = line_of(chain, t - 1);
+            build_R(line, Bbuf(Bc0, t - 2), t > 1 ? xg + (size_t)line_of(chain, t - 2) * xline : nullptr, true, false);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            gemm_Z(line);
+          }
+        __syncthreads(); // M1 (also: both chains' last Z are in the workspace)
+        __syncthreads(); // M2: V_mid is in the workspace
+        if (chain == 0)
+          {
+            // R_mid = F_mid - B^T Z(mid-1) - B'^T Z(mid+1); the bands are the last B of each chain
+            const double *B0 = Bbuf(Bc0, n0 - 1);
+            double       *ob = ocb + MP * ncs + MP + 3 * bsz; // other chain's Bc0
+            const double *B1 = Bbuf(ob, n1 - 1);
+            build_R(mid, B0, n0 > 0 ? xg + (size_t)(mid - 1) * xline : nullptr, true, false);
+            __builtin_amdgcn_wave_barrier();
+            if (n1 > 0)
+              build_R(mid, B1, xg + (size_t)(mid + 1) * xline, false, true);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            gemm_Z(mid); // X_mid
+          }
+        __syncthreads(); // M3
+      }
+
+    // ------------------------------ backward substitution -------------------------
+    // from the meeting line outwards, both chains at once; each chain = 2 waves (128 threads).
+    // Band entries of the next line are fetched (stencil planes, workspace latency) before the
+    // GEMM of the current line and written to the other band buffer after it.
+    {
+      const int t128 = (wave >> 1) * 64 + lane, w2 = wave >> 1;
+      const int tiles_i = (m + 15) >> 4, tiles_j = (nc + 15) >> 4;
+      constexpr int NBV = (MP * BW + 127) / 128;
+      double        bv[NBV];
+      auto fetch_B = [&](int line) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < NBV; ++q)
+          {
+            const int idx = t128 + 128 * q, i = idx / BW, o = idx - i * BW - W;
+            bv[q] = (idx < m * BW) ? coupling<S>(st, A.nn_max, npx, tr, m, line, i, dl, o) : 0.0;
+          }
+      };
+      auto store_B = [&](double *Bdst) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < NBV; ++q)
+          {
+            const int idx = t128 + 128 * q, i = idx / BW, oi = idx - i * BW;
+            if (idx < m * BW)
+              Bdst[(i + W) * BWP + oi] = bv[q];
+          }
+      };
+      const int tstart = (A.diag & 16) ? -1 : nstp - 1;
+      if (tstart >= 0 && tstart < nmy)
+        {
+          fetch_B(line_of(chain, tstart));
+          store_B((tstart & 1) ? Bc1 : Bc0);
+        }
+      else if (nmy > 0 && tstart >= 0)
+        {
+          fetch_B(line_of(chain, nmy - 1)); // shorter chain: its first active step is nmy-1
+          store_B(((nmy - 1) & 1) ? Bc1 : Bc0);
+        }
+      for (int t = tstart; t >= 0; --t)
+        {
+          const bool    active = t < nmy;
+          const int     line = line_of(chain, t), prev = line_of(chain, t + 1); // prev: solved before (mid first)
+          const double *Bn = (t & 1) ? Bc1 : Bc0;
+          __syncthreads(); // bands of this line are in LDS, X(prev) is in the workspace
+          if (active && t > 0)
+            fetch_B(line_of(chain, t - 1));
+          if (active)
+            {
+              // Y = B(line -> prev) X(prev): lane = (column r, quarter of the rows), sliding window
+              const double *xp = xg + (size_t)prev * xline;
+              const int     qr = t128 >> 5, i_lo = (qr * m) >> 2, i_hi = ((qr + 1) * m) >> 2;
+              for (int r = t128 & 31; r < nc; r += 32)
+                {
+                  double win[BW];
+#pragma unroll
+                  for (int e = 0; e < BW; ++e)
+                    {
+                      const int p = i_lo + e - W;
+                      win[e]      = (p >= 0 && p < m) ? xp[p * ncg + r] : 0.0;
+                    }
+                  for (int i = i_lo; i < i_hi; ++i)
+                    {
+                      const int    pn    = i + 1 + W;
+                      const double xnext = (pn < m) ? xp[pn * ncg + r] : 0.0;
+                      double       v     = 0.0;
+#pragma unroll
+                      for (int o = 0; o < BW; ++o)
+                        v = fma(Bn[(i + W) * BWP + o], win[o], v);
+                      Rb[i * ncs + r] = v;
+#pragma unroll
+                      for (int e = 0; e + 1 < BW; ++e)
+                        win[e] = win[e + 1];
+                      win[BW - 1] = xnext;
+                    }
+                }
+            }
+          __syncthreads();
+          if (active)
+            {
+              const double *vl = vg + (size_t)line * vline;
+              double       *xl = xg + (size_t)line * xline;
+              for (int tt = w2; tt < tiles_i * tiles_j; tt += 2)
+                {
+                  const int ti = tt / tiles_j, tj = tt - ti * tiles_j;
+                  const int col = 16 * tj + (lane & 15);
+                  const int arow = min(16 * ti + (lane & 15), MP - 1);
+                  double    zl[4];
+#pragma unroll
+                  for (int r = 0; r < 4; ++r)
+                    {
+                      const int row = 16 * ti + (lane >> 4) + 4 * r;
+                      zl[r]         = (row < m && col < nc) ? xl[row * ncg + col] : 0.0;
+                    }
+                  double4_t     acc = {0.0, 0.0, 0.0, 0.0};
+                  const double *ap  = vl + arow * MP + (lane >> 4);
+                  const double *bp  = Rb + (lane >> 4) * ncs + col;
+                  double        av[MP / 4];
+#pragma unroll
+                  for (int kk = 0; kk < MP / 4; ++kk)
+                    av[kk] = ap[4 * kk];
+#pragma unroll
+                  for (int kk = 0; kk < MP / 4; ++kk)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bp[4 * kk * ncs], acc, 0, 0, 0);
+#pragma unroll
+                  for (int r = 0; r < 4; ++r)
+                    {
+                      const int row = 16 * ti + (lane >> 4) + 4 * r;
+                      if (row < m && col < nc)
+                        xl[row * ncg + col] = zl[r] - acc[r];
+                    }
+                }
+              if (t > 0)
+                store_B(((t - 1) & 1) ? Bc1 : Bc0);
+            }
+          // the next iteration's first barrier orders the X and band writes before their readers
+        }
+    }
+  }
+
+} // namespace
+
+size_t slod_solve_tw_lds_bytes(int S, int m_max, int nc_max)
+{
+  // must mirror the carve-up at the top of k_solve_tw
+  const int    T = slod_solve_ws_tile(m_max), W = 2 * S - 1, BW = 2 * W + 1, MP = 8 * T;
+  const int    ncs = (nc_max + 1) & ~1, bsz = ((MP + 2 * W) * (BW + 1) + 1) & ~1;
+  (void)m_max;
+  const size_t chsz = (size_t)MP * ncs + MP + 6 * (size_t)bsz;
+  return ((2 * chsz * sizeof(double) + 2 * (size_t)nc_max * sizeof(int)) + 15) & ~(size_t)15;
+}
+
+template <int T, int S>
+static hipError_t launch_tw_TS(const SlodKernelArgs &a, int n_patches, size_t lds, hipStream_t st)
+{
+  const void *fn = reinterpret_cast<const void *>(k_solve_tw<T, S>);
+  hipError_t  e  = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess)
+    return e;
+  if (getenv("SLOD_DEBUG"))
+    {
+      int nb = 0;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, lds);
+      fprintf(stderr, "[slod] k_solve_tw<%d,%d>: %d patches, lds %zu B, occupancy %d blocks/CU\n", T, S, n_patches,
+              lds, nb);
+    }
+  hipLaunchKernelGGL((k_solve_tw<T, S>), dim3(n_patches), dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+
+template <int S>
+static hipError_t launch_tw_S(const SlodKernelArgs &a, int n_patches, size_t lds, hipStream_t st)
+{
+  switch (slod_solve_ws_tile(a.m_max))
+    {
+      case 2:
+        return launch_tw_TS<2, S>(a, n_patches, lds, st);
+      case 3:
+        return launch_tw_TS<3, S>(a, n_patches, lds, st);
+      case 4:
+        return launch_tw_TS<4, S>(a, n_patches, lds, st);
+      case 5:
+        return launch_tw_TS<5, S>(a, n_patches, lds, st);
+      case 6:
+        return launch_tw_TS<6, S>(a, n_patches, lds, st);
+      case 8:
+        return launch_tw_TS<8, S>(a, n_patches, lds, st);
+      case 10:
+        return launch_tw_TS<10, S>(a, n_patches, lds, st);
+      case 12:
+        return launch_tw_TS<12, S>(a, n_patches, lds, st);
+      case 14:
+        return launch_tw_TS<14, S>(a, n_patches, lds, st);
+      default:
+        return hipErrorInvalidValue;
+    }
+}
+
+hipError_t slod_launch_solve_tw(int S, const SlodKernelArgs &a, int n_patches, size_t lds, hipStream_t st)
+{
+  return S == 1 ? launch_tw_S<1>(a, n_patches, lds, st) : launch_tw_S<2>(a, n_patches, lds, st);
+}
