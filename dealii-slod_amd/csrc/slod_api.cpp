@@ -243,6 +243,9 @@ namespace
     a.nc_max    = p->nc_max;
     a.ms        = p->ws_m;
     a.m_fused   = 0; // set by slod_launch_solve when the wave-specialised kernel runs
+    a.nb_buf    = p->nb_buf;
+    a.nf_max    = p->nf_max;
+    a.fuse_select = 0; // set by slod_launch_solve
     a.basis     = d_basis;
     a.premult   = d_premult;
     a.status    = p->d_status;
@@ -611,10 +614,10 @@ int slod_plan_execute(slod_plan *p, double *d_basis, double *d_premult, void *hi
       if (e == hipSuccess)
         e = hipEventRecord(ev[1], st);
       if (e == hipSuccess)
-        e = slod_launch_solve(s, a, cnt, st); // sets a.m_fused
+        e = slod_launch_solve(s, a, cnt, st); // sets a.m_fused, a.fuse_select
       if (e == hipSuccess)
         e = hipEventRecord(ev[2], st);
-      if (e == hipSuccess)
+      if (e == hipSuccess && !a.fuse_select)
         e = slod_launch_select(s, a, cnt, p->nb_buf, p->nf_max, st);
       if (e == hipSuccess)
         e = hipEventRecord(ev[3], st);
@@ -624,6 +627,20 @@ int slod_plan_execute(slod_plan *p, double *d_basis, double *d_premult, void *hi
   p->ran = true;
   ++p->n_exec;
   return SLOD_OK;
+}
+
+// timing experiments only (not part of include/slod.h): the per-patch scratch block `ms` of the
+// first workspace chunk, which the kernels fill with clock stamps under SLOD_DIAG bit 20
+int slod_debug_read_ms(slod_plan *p, double *out, size_t count)
+{
+  if (!p || !out)
+    return SLOD_ERR_ARGUMENT;
+  const size_t have = p->chunk * (size_t)p->nc_max * p->nc_max;
+  (void)hipSetDevice(p->h->cfg.device);
+  (void)hipDeviceSynchronize();
+  return hipMemcpy(out, p->ws_m, std::min(count, have) * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess
+             ? SLOD_OK
+             : SLOD_ERR_DEVICE;
 }
 
 int slod_plan_profile(slod_plan *p, int depth)

@@ -53,6 +53,9 @@ struct SlodKernelArgs
   int32_t nc_max;
   double *ms;       // per patch M = P^T A^-1 P / H^2 accumulated by k_solve_ws (nc_max^2 doubles)
   int32_t m_fused;  // 1: k_select reads M from ms instead of recomputing it from X
+  int32_t nb_buf;   // rows of the selection stage's boundary-trace buffer
+  int32_t nf_max;   // largest n_fine of the plan
+  int32_t fuse_select; // set by slod_launch_solve: the solve kernel also ran the selection stage
   // outputs
   double  *basis;
   double  *premult;

@@ -7,6 +7,7 @@
 hipError_t slod_launch_solve(int S, SlodKernelArgs &a, int n_patches, hipStream_t st)
 {
   a.m_fused = 0;
+  a.fuse_select = 0;
   // Kernel choice (SLOD_SOLVE=tw|ws|coop forces one):
   //   tw   twisted + wave-specialised (default): two GJ waves + two helper waves per patch
   //   ws   wave-specialised, one chain: one GJ wave + three helpers (keeps V, Z in LDS)
@@ -17,7 +18,13 @@ hipError_t slod_launch_solve(int S, SlodKernelArgs &a, int n_patches, hipStream_
     const bool  want_tw = !sel || !strcmp(sel, "tw"), want_ws = !sel || !strcmp(sel, "ws") || !strcmp(sel, "tw");
     if (fits && want_tw && slod_solve_tw_lds_bytes(S, a.m_max, a.nc_max) <= 160 * 1024)
       {
-        const size_t lds = slod_solve_tw_lds_bytes(S, a.m_max, a.nc_max);
+        size_t lds = slod_solve_tw_lds_bytes(S, a.m_max, a.nc_max);
+        // the selection stage runs in the same launch (scalar problems; SLOD_FUSE_SELECT=0 splits it off)
+        const char  *fs   = getenv("SLOD_FUSE_SELECT");
+        const size_t lds2 = slod_select_lds_bytes(S, a.nb_buf, a.nc_max, a.nf_max);
+        a.fuse_select     = (S == 1 && !(fs && !atoi(fs)) && lds2 <= 64 * 1024) ? 1 : 0;
+        if (a.fuse_select && lds2 > lds)
+          lds = lds2;
         return slod_launch_solve_tw(S, a, n_patches, lds, st);
       }
     if (fits && want_ws && slod_solve_ws_lds_bytes(S, a.m_max, a.nc_max) <= 160 * 1024)

@@ -1,628 +1,13 @@
-// k_select: coarse Schur block, (S)LOD selection, normalisation, premultiplication.
-#include "slod_common.hip.h"
+// k_select: stand-alone launch of the selection stage (select_patch, slod_select.hip.h).
+#include "slod_select.hip.h"
 
 namespace
 {
-  // ---------------------------------------------------------------------------------
-  // K3: coarse Schur block, (S)LOD selection, normalisation, premultiplication
-  // ---------------------------------------------------------------------------------
-
-  // The SLOD selection needs  d = -(BD')^+ b0  (LOD.cc:656-671) and, only if ||d||_inf >= 0.5
-  // or a singular value falls under the 1e-15 cutoff, the singular triplets of BD' for the
-  // truncation loop (LOD.cc:703-725).  So: Householder QR of [BD' | b0] in LDS first.  With
-  // R (n x n) and c = Q^T b0:  d = -R^{-1} c.  cond(R) <= ||R||_F ||R^{-1}||_F =: kF is a
-  // rigorous bound, so kF^2 < 1e14 proves that no singular value of G = R^T R is cut, and
-  // ||d||_inf < 0.5 (with a 1e-9 guard band) proves the loop removes nothing: the fast path
-  // takes exactly the reference's decisions.  Otherwise a one-sided Jacobi SVD of R (same
-  // singular values / right vectors as BD', u_j^T g = (R v_j).c) replays the loop literally.
   template <int S>
   __global__ __launch_bounds__(256) void k_select(const SlodKernelArgs A, int nb_max, int nf_max)
   {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const SlodPatchDesc d   = A.desc[blockIdx.x];
-    const int           tid = threadIdx.x;
-    const int           nc = d.n_c, nb = d.n_b, n = A.n_sub;
-    const int           ncm = A.nc_max, ldm = ncm + 1;
-    const int           mm = A.m_max, ncs = A.nc_max;
-    const bool          tr  = (d.flags & SLOD_F_TRANSPOSED) != 0;
-    const bool          lod = (d.flags & SLOD_F_LOD) != 0;
-    const int           npx = d.nx + 1, nn = npx * (d.ny + 1), nf = S * nn;
-
-    double *Ms   = smem;                 // [ncm][ldm]  M, then D = M^-1
-    double *Vj   = Ms + ncm * ldm;       // [ncm][ncm]  R^-1 / Jacobi rotations
-    double *BD   = Vj + ncm * ncm;       // [nb_max][ncm]  (nb_max = buffer rows, see TSQR below)
-    double *phis = BD;                   // [nf_max] aliases BD (dead once gamma is known)
-    double *sig  = BD + max(nb_max * ncm, nf_max); // [ncm]
-    double *utg  = sig + ncm;
-    double *gam  = utg + ncm;
-    double *cvec = gam + ncm;
-    double *rowk = cvec + ncm;           // [ncm]
-    double *red  = rowk + ncm;           // [8]
-    int    *colk = reinterpret_cast<int *>(red + 8); // [2][ncm] cell of column
-    int    *ord  = colk + 2 * ncm;       // [ncm]
-    int    *flag = ord + ncm;            // [4]
-
-    const double *st    = A.st + (size_t)blockIdx.x * A.st_stride;
-    const double *xg    = A.xs + (size_t)blockIdx.x * A.x_stride;
-    const size_t  xline = (size_t)mm * ncs;
-    const int     wave = tid >> 6, lane = tid & 63, grp = tid >> 4, l16 = tid & 15;
-
-    // row of X for dof (ix,iy,comp), nullptr on the patch boundary (X_B = 0, LOD.cc:512-518)
-    auto xrow = [&](int ix, int iy, int comp) -> const double * {
-      if (ix <= 0 || ix >= d.nx || iy <= 0 || iy >= d.ny)
-        return nullptr;
-      const int l = tr ? ix - 1 : iy - 1, pos = tr ? iy - 1 : ix - 1;
-      return xg + (size_t)l * xline + (size_t)(pos * S + comp) * ncs;
-    };
-    // entry of the un-zeroed P^T / (h^2/4)
-    auto ptw = [&](int ix, int iy, int comp, int col) -> double {
-      if (S == 1)
-        {
-          const int jx = ix - colk[col] * n, jy = iy - colk[ncm + col] * n;
-          if (jx < 0 || jx > n || jy < 0 || jy > n)
-            return 0.0;
-          return ((jx == 0 || jx == n) ? 1.0 : 2.0) * ((jy == 0 || jy == n) ? 1.0 : 2.0);
-        }
-      return pt_weight<S>(d, n, A.quirk, ix, iy, comp, col);
-    };
-    auto block_sum = [&](double v) -> double { // all threads get the sum
-      for (int off = 32; off > 0; off >>= 1)
-        v += __shfl_xor(v, off, 64);
-      __syncthreads();
-      if (lane == 0)
-        red[wave] = v;
-      __syncthreads();
-      return red[0] + red[1] + red[2] + red[3];
-    };
-
-    for (int c = tid; c < nc; c += 256)
-      {
-        int kx, ky;
-        cell_of_col(d, c / S, kx, ky);
-        colk[c]       = kx;
-        colk[ncm + c] = ky;
-      }
-    __syncthreads();
-
-    // ---- M = P^T X / H^dim (LOD.cc:548-551).  X rows come from the global workspace: the
-    //      inner loop has no control dependence (clamped address, zero weight on the patch
-    //      boundary where X = 0) so its n+1 loads are in flight together.
-    if (A.m_fused)
-      {
-        const double *mg = A.ms + (size_t)blockIdx.x * A.nc_max * A.nc_max;
-        for (int idx = tid; idx < nc * nc; idx += 256)
-          Ms[(idx / nc) * ldm + (idx % nc)] = mg[idx];
-      }
-    for (int idx = tid; idx < ((A.diag & 64) || A.m_fused ? 0 : nc * nc); idx += 256)
-      {
-        const int a = idx / nc, b = idx - a * nc;
-        const int kx = colk[a], ky = colk[ncm + a];
-        double    acc = 0.0;
-        if (S == 1 || !A.quirk)
-          {
-            const int ca = a % S;
-            for (int jy = 0; jy <= n; ++jy)
-              {
-                const int iy = ky * n + jy;
-                if (iy <= 0 || iy >= d.ny)
-                  continue;
-                double part = 0.0;
-#pragma unroll 9
-                for (int jx = 0; jx <= n; ++jx)
-                  {
-                    const int    ix  = kx * n + jx;
-                    const int    ixc = min(max(ix, 1), d.nx - 1);
-                    const int    l = tr ? ixc - 1 : iy - 1, pos = tr ? iy - 1 : ixc - 1;
-                    const double x = xg[(size_t)l * xline + (size_t)(pos * S + ca) * ncs + b];
-                    const double w = (ix > 0 && ix < d.nx) ? ((jx == 0 || jx == n) ? 1.0 : 2.0) : 0.0;
-                    part           = fma(w, x, part);
-                  }
-                acc = fma((jy == 0 || jy == n) ? 1.0 : 2.0, part, acc);
-              }
-          }
-        else
-          {
-            for (int jy = 0; jy <= n; ++jy)
-              for (int jx = 0; jx <= n; ++jx)
-                {
-                  const int ix = kx * n + jx, iy = ky * n + jy;
-#pragma unroll
-                  for (int c = 0; c < S; ++c)
-                    {
-                      const double *xr = xrow(ix, iy, c);
-                      if (xr)
-                        acc = fma(pt_weight<S>(d, n, A.quirk, ix, iy, c, a), xr[b], acc);
-                    }
-                }
-          }
-        Ms[a * ldm + b] = acc * A.scale * A.invH2;
-      }
-    __syncthreads();
-
-    // ---- D = M^{-1} (LOD.cc:553) by the symmetric sweep; M is SPD
-    for (int k = 0; k < ((A.diag & 128) ? 0 : nc); ++k)
-      {
-        for (int j = tid; j < nc; j += 256)
-          rowk[j] = Ms[k * ldm + j];
-        __syncthreads();
-        const double piv = rowk[k];
-        if (tid == 0 && !(piv > 0.0) && !A.diag)
-          atomicOr(A.status, 2);
-        const double p = 1.0 / piv;
-        for (int idx = tid; idx < nc * nc; idx += 256)
-          {
-            const int    i = idx / nc, j = idx - i * nc;
-            const double ri = rowk[i], rj = rowk[j];
-            double       v;
-            if (i == k)
-              v = (j == k) ? -p : rj * p;
-            else if (j == k)
-              v = ri * p;
-            else
-              v = fma(-(ri * rj), p, Ms[i * ldm + j]);
-            Ms[i * ldm + j] = v;
-          }
-        __syncthreads();
-      }
-    for (int idx = tid; idx < nc * nc; idx += 256)
-      {
-        const int i = idx / nc, j = idx - i * nc;
-        Ms[i * ldm + j] = -Ms[i * ldm + j];
-      }
-    __syncthreads();
-    double *Ds = Ms;
-
-    for (int dsel = 0; dsel < S; ++dsel)
-      {
-        for (int j = tid; j < nc; j += 256)
-          gam[j] = (j == dsel) ? 1.0 : 0.0;
-        if (!lod)
-          {
-            // ---- BD = (S_BI X_I - P^T_B) D (LOD.cc:609-618), built in row chunks that fit the
-            //      LDS buffer (nbuf rows) and reduced by Householder QR chunk after chunk
-            //      (TSQR): after every chunk the top nn1 rows hold the R factor of all rows
-            //      seen so far and c = Q^T b0 sits in column dsel.
-            const int nn1 = nc - 1; // columns of BD' = BD without column dsel
-            auto      cix = [&](int j) { return j < dsel ? j : j + 1; };
-            const int nbuf = nb_max;
-            int       nr   = 0;     // rows of the matrix the SVD fallback works on
-            bool      need_svd = true, singular = false, did_qr = false;
-            int       filled = 0;
-            for (int r0 = 0; r0 < nb;)
-              {
-                const int take = min(nb - r0, nbuf - filled);
-                // stencil rows instead of the dense S_boundary
-                for (int idx = tid; idx < ((A.diag & 256) ? 0 : take * nc); idx += 256)
-                  {
-                    const int br = idx / nc, c = idx - br * nc;
-                    const int bi = r0 + br;
-                    const int bn = bi / S, ca = bi - bn * S;
-                    int       ix, iy;
-                    boundary_node(d, bn, ix, iy);
-                    double acc = -A.scale * ptw(ix, iy, ca, c);
-#pragma unroll
-                    for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-                      for (int dx = -1; dx <= 1; ++dx)
-                        {
-                          const int  jx = ix + dx, jy = iy + dy;
-                          const bool in = (jx > 0 && jx < d.nx && jy > 0 && jy < d.ny);
-                          const int  jxc = min(max(jx, 1), d.nx - 1), jyc = min(max(jy, 1), d.ny - 1);
-                          const int  dir = (dy + 1) * 3 + dx + 1;
-                          const int  l = tr ? jxc - 1 : jyc - 1, pos = tr ? jyc - 1 : jxc - 1;
-#pragma unroll
-                          for (int cb = 0; cb < S; ++cb)
-                            {
-                              const double sv = in ? st[(size_t)((dir * S + ca) * S + cb) * A.nn_max + ix + iy * npx] : 0.0;
-                              acc = fma(sv, xg[(size_t)l * xline + (size_t)(pos * S + cb) * ncs + c], acc);
-                            }
-                        }
-                    BD[(filled + br) * ncm + c] = acc;
-                  }
-                __syncthreads();
-                // rows <- rows * D, one wave per row, row held across lanes (nc <= 64)
-                for (int br = wave; br < take; br += 4)
-                  {
-                    const int    row  = filled + br;
-                    const double mine = (lane < nc) ? BD[row * ncm + lane] : 0.0;
-                    double       acc  = 0.0;
-                    for (int j = 0; j < nc; ++j)
-                      {
-                        const double bj = __shfl(mine, j, 64);
-                        acc             = fma(bj, (lane < nc) ? Ds[j * ldm + lane] : 0.0, acc);
-                      }
-                    if (lane < nc)
-                      BD[row * ncm + lane] = acc;
-                  }
-                __syncthreads();
-                r0 += take;
-                const int rows = filled + take;
-                nr             = rows;
-                if (rows < nn1 || (A.diag & 512))
-                  {
-                    filled = rows; // fewer rows than columns so far
-                    if (filled >= nbuf)
-                      break;       // cannot happen: nbuf > nn1
-                    continue;
-                  }
-                // ---- Householder QR of the rows x [BD' | b0] block, in place.  One barrier per
-                // reflector: the 16-lane group that updates the NEXT pivot column also
-                // accumulates its norm below the diagonal (sigma of the next step).
-                did_qr = true;
-                {
-                  double part = 0.0;
-                  for (int r = tid; r < rows; r += 256)
-                    {
-                      const double x = BD[r * ncm + cix(0)];
-                      part           = fma(x, x, part);
-                    }
-                  const double s00 = block_sum(part);
-                  if (tid == 0)
-                    sig[0] = s00;
-                  __syncthreads();
-                }
-                for (int k = 0; k < nn1; ++k)
-                  {
-                    const int    ck    = cix(k);
-                    const double sigma = sig[k & 1];
-                    if (!(sigma > 0.0))
-                      {
-                        // zero column (rank deficient): no reflector; the next column's norm
-                        if (r0 >= nb)
-                          singular = true; // replayed through the SVD
-                        if (k + 1 < nn1)
-                          {
-                            double part = 0.0;
-                            for (int r = k + 1 + tid; r < rows; r += 256)
-                              {
-                                const double x = BD[r * ncm + cix(k + 1)];
-                                part           = fma(x, x, part);
-                              }
-                            const double sn = block_sum(part);
-                            if (tid == 0)
-                              sig[(k + 1) & 1] = sn;
-                          }
-                        __syncthreads();
-                        continue;
-                      }
-                    const double x0    = BD[k * ncm + ck];
-                    const double sq    = sigma * fast_rsqrt(sigma);
-                    const double alpha = (x0 >= 0.0) ? -sq : sq;
-                    const double v0    = x0 - alpha;
-                    const double beta  = fast_rcp(sigma - alpha * x0); // 2 / v^T v
-                    // apply H = I - beta v v^T to the trailing columns and to b0
-                    for (int t = grp; t < nn1 - k; t += 16)
-                      {
-                        const int cj = (t == nn1 - k - 1) ? dsel : cix(k + 1 + t);
-                        double    sd = 0.0;
-                        for (int r = k + l16; r < rows; r += 16)
-                          {
-                            const double vr = (r == k) ? v0 : BD[r * ncm + ck];
-                            sd              = fma(vr, BD[r * ncm + cj], sd);
-                          }
-                        sd = group16_sum(sd) * beta;
-                        double nxt = 0.0;
-                        for (int r = k + l16; r < rows; r += 16)
-                          {
-                            const double vr = (r == k) ? v0 : BD[r * ncm + ck];
-                            const double nv = fma(-sd, vr, BD[r * ncm + cj]);
-                            BD[r * ncm + cj] = nv;
-                            if (r > k)
-                              nxt = fma(nv, nv, nxt);
-                          }
-                        if (t == 0 && k + 1 < nn1) // cj is the next pivot column
-                          {
-                            nxt = group16_sum(nxt);
-                            if (l16 == 0)
-                              sig[(k + 1) & 1] = nxt;
-                          }
-                      }
-                    __syncthreads();
-                    if (tid == 0)
-                      BD[k * ncm + ck] = alpha; // R_kk (after the barrier: x0 was read from here)
-                  }
-                // clear the strict lower triangle of the R block (dead reflector storage): the
-                // next chunk's QR and the SVD fallback read it as part of the matrix
-                for (int idx = tid; idx < nn1 * nn1; idx += 256)
-                  {
-                    const int r = idx / nn1, j = idx - r * nn1;
-                    if (r > j)
-                      BD[r * ncm + cix(j)] = 0.0;
-                  }
-                for (int r = nn1 + tid; r < rows; r += 256)
-                  for (int j = 0; j < nn1; ++j)
-                    BD[r * ncm + cix(j)] = 0.0;
-                __syncthreads();
-                filled = nn1;
-                nr     = nn1;
-              }
-            if (did_qr && !(A.diag & 512))
-              {
-                if (!singular)
-                  {
-                    // R^{-1} by columns (thread j solves R x = e_j), Frobenius norms, d = -R^{-1} c
-                    double fr = 0.0, fi = 0.0;
-                    if (tid < nn1)
-                      {
-                        const int j = tid;
-                        for (int i = 0; i <= j; ++i)
-                          {
-                            const double r = BD[i * ncm + cix(j)];
-                            fr             = fma(r, r, fr);
-                          }
-                        Vj[j * nn1 + j] = 1.0 / BD[j * ncm + cix(j)];
-                        for (int i = j - 1; i >= 0; --i)
-                          {
-                            double s = 0.0;
-                            for (int k2 = i + 1; k2 <= j; ++k2)
-                              s = fma(BD[i * ncm + cix(k2)], Vj[k2 * nn1 + j], s);
-                            Vj[i * nn1 + j] = -s / BD[i * ncm + cix(i)];
-                          }
-                        for (int i = 0; i <= j; ++i)
-                          fi = fma(Vj[i * nn1 + j], Vj[i * nn1 + j], fi);
-                      }
-                    const double nr2 = block_sum(fr), ni2 = block_sum(fi);
-                    double       del = 0.0;
-                    if (tid < nn1)
-                      {
-                        for (int j = tid; j < nn1; ++j)
-                          del = fma(-Vj[tid * nn1 + j], BD[j * ncm + dsel], del);
-                        rowk[tid] = del;
-                      }
-                    double dmax = fabs(del);
-                    for (int off = 32; off > 0; off >>= 1)
-                      dmax = fmax(dmax, __shfl_xor(dmax, off, 64));
-                    __syncthreads();
-                    if (lane == 0)
-                      red[4 + wave] = dmax;
-                    __syncthreads();
-                    const double dinf = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
-                    if (nr2 * ni2 < 1e14 && dinf < 0.5 - 1e-9)
-                      {
-                        need_svd = false;
-                        if (tid < nn1)
-                          gam[cix(tid)] = rowk[tid];
-                      }
-                  }
-              }
-            if (need_svd && !(A.diag & (512 | 4096)))
-              {
-                // ---- one-sided Jacobi SVD (the reference's singular triplets are needed).
-                // After the QR the sweeps run on L = R^T (Drmac/Veselic: much faster convergence
-                // than on R): L J = W with orthogonal columns w_j = sigma_j v_j (v_j = right
-                // singular vectors of R = those of BD'), J = left singular vectors of R, so
-                // sigma_j(G) = |w_j|^2, u_j^T g = sigma_j (J_j . c), and the reference's term
-                // v_j (u_j^T g) / sigma_j(G) = w_j (J_j . c) / |w_j|^2.  Without a QR (fewer rows
-                // than columns) the sweeps run on BD' itself: W = BD' V, term = V_j (w_j . b0)/|w_j|^2.
-                const bool tposed = did_qr && nbuf >= 2 * nn1;
-                double    *Wm     = BD;              // matrix whose columns are rotated
-                int        wr     = nr;              // its rows
-                if (tposed)
-                  {
-                    Wm = BD + (size_t)nn1 * ncm;     // rows nn1..2nn1-1 of the buffer are free now
-                    for (int idx = tid; idx < nn1 * nn1; idx += 256)
-                      {
-                        const int i = idx / nn1, j = idx - i * nn1;       // L[i][j] = R[j][i]
-                        Wm[i * ncm + j] = (j <= i) ? BD[j * ncm + cix(i)] : 0.0;
-                      }
-                    wr = nn1;
-                  }
-                auto wcol = [&](int j) { return tposed ? j : cix(j); };
-                const int nev = (nn1 + 1) & ~1;
-                for (int idx = tid; idx < nn1 * nn1; idx += 256)
-                  Vj[idx] = ((idx / nn1) == (idx % nn1)) ? 1.0 : 0.0;
-                // Frobenius norm^2 (rotation invariant): columns below 1e-22 of it are numerically
-                // zero -- seven orders under the reference's 1e-15 cutoff on sigma(G) -- and are
-                // not rotated (two noise columns never pass the relative test and would keep
-                // every sweep busy on rank-deficient rim patches)
-                double fro = 0.0;
-                for (int idx = tid; idx < wr * nn1; idx += 256)
-                  {
-                    const double w = Wm[(idx / nn1) * ncm + wcol(idx % nn1)];
-                    fro            = fma(w, w, fro);
-                  }
-                const double tiny = 1e-22 * block_sum(fro);
-                for (int sweep = 0; sweep < ((A.diag & 8192) ? 3 : 40); ++sweep)
-                  {
-                    if (tid == 0)
-                      flag[0] = 0;
-                    __syncthreads();
-                    for (int round = 0; round < nev - 1; ++round)
-                      {
-                        for (int pr = grp; pr < nev / 2; pr += 16)
-                          {
-                            int pa, pb;
-                            if (pr == 0)
-                              {
-                                pa = nev - 1;
-                                pb = round;
-                              }
-                            else
-                              {
-                                pa = round + pr;
-                                pa = pa >= nev - 1 ? pa - (nev - 1) : pa;
-                                pb = round - pr;
-                                pb = pb < 0 ? pb + (nev - 1) : pb;
-                              }
-                            if (pa >= nn1 || pb >= nn1)
-                              continue;
-                            const int p = pa < pb ? pa : pb, q = pa < pb ? pb : pa;
-                            const int cp = wcol(p), cq = wcol(q);
-                            double    app = 0, aqq = 0, apq = 0;
-                            for (int r = l16; r < wr; r += 16)
-                              {
-                                const double wp = Wm[r * ncm + cp], wq = Wm[r * ncm + cq];
-                                app = fma(wp, wp, app);
-                                aqq = fma(wq, wq, aqq);
-                                apq = fma(wp, wq, apq);
-                              }
-                            app = group16_sum(app);
-                            aqq = group16_sum(aqq);
-                            apq = group16_sum(apq);
-                            if (apq == 0.0 || apq * apq <= 1e-30 * (app * aqq) || fmin(app, aqq) <= tiny)
-                              continue;
-                            // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (aqq-app)/(2 apq),
-                            // written without the division by apq; c = 1/sqrt(1+t^2), s = c t
-                            const double dd = aqq - app;
-                            const double hh = fma(dd, dd, 4.0 * apq * apq);
-                            const double hy = hh * fast_rsqrt(hh); // sqrt(dd^2 + 4 apq^2)
-                            const double t  = (dd >= 0.0 ? 2.0 : -2.0) * apq * fast_rcp(fabs(dd) + hy);
-                            const double cs = fast_rsqrt(fma(t, t, 1.0)), sn = cs * t;
-                            for (int r = l16; r < wr; r += 16)
-                              {
-                                const double wp = Wm[r * ncm + cp], wq = Wm[r * ncm + cq];
-                                Wm[r * ncm + cp] = cs * wp - sn * wq;
-                                Wm[r * ncm + cq] = sn * wp + cs * wq;
-                              }
-                            for (int r = l16; r < nn1; r += 16)
-                              {
-                                const double vp = Vj[r * nn1 + p], vq = Vj[r * nn1 + q];
-                                Vj[r * nn1 + p] = cs * vp - sn * vq;
-                                Vj[r * nn1 + q] = sn * vp + cs * vq;
-                              }
-                            if (l16 == 0)
-                              flag[0] = 1;
-                          }
-                        __syncthreads();
-                      }
-                    const int any = flag[0];
-                    __syncthreads();
-                    if (!any)
-                      break;
-                  }
-                // sig_j = sigma_j(G); utg_j = coefficient of the j-th term's vector
-                for (int j = tid; j < nn1; j += 256)
-                  {
-                    const int cj = wcol(j);
-                    double    ss = 0, wb = 0;
-                    for (int r = 0; r < wr; ++r)
-                      {
-                        const double w = Wm[r * ncm + cj];
-                        ss             = fma(w, w, ss);
-                        if (!tposed)
-                          wb = fma(w, BD[r * ncm + dsel], wb);           // w_j . b0
-                      }
-                    if (tposed)
-                      for (int i = 0; i < nn1; ++i)
-                        wb = fma(Vj[i * nn1 + j], BD[i * ncm + dsel], wb); // J_j . c
-                    sig[j] = ss;
-                    utg[j] = wb;
-                  }
-                __syncthreads();
-                // term vectors: V_j (no QR) or w_j (after the QR); element a2 of term j
-                auto tvec = [&](int a2, int j) { return tposed ? Wm[a2 * ncm + j] : Vj[a2 * nn1 + j]; };
-                if (tid == 0)
-                  {
-                    // descending sigma, pseudo-inverse cutoff (LOD.cc:667)
-                    for (int j = 0; j < nn1; ++j)
-                      ord[j] = j;
-                    for (int a2 = 1; a2 < nn1; ++a2)
-                      {
-                        const int o = ord[a2];
-                        int       b2 = a2 - 1;
-                        while (b2 >= 0 && sig[ord[b2]] < sig[o])
-                          {
-                            ord[b2 + 1] = ord[b2];
-                            --b2;
-                          }
-                        ord[b2 + 1] = o;
-                      }
-                    const double s0 = sig[ord[0]];
-                    for (int j = 0; j < nn1; ++j)
-                      utg[j] = (sig[j] > 1e-15 * s0) ? utg[j] / sig[j] : 0.0;
-                  }
-                __syncthreads();
-                // d = -G^+ g (LOD.cc:669-671), one thread per component
-                double del = 0.0;
-                if (tid < nn1)
-                  for (int j = 0; j < nn1; ++j)
-                    del = fma(-tvec(tid, j), utg[j], del);
-                // the 0.5-loop (LOD.cc:703-725): put the smallest remaining triplet back while
-                // ||d||_inf >= 0.5 (the test precedes every removal)
-                for (int r = nn1 - 1; r >= 0; --r)
-                  {
-                    double dmax = (tid < nn1) ? fabs(del) : 0.0;
-                    for (int off = 32; off > 0; off >>= 1)
-                      dmax = fmax(dmax, __shfl_xor(dmax, off, 64));
-                    __syncthreads();
-                    if (lane == 0)
-                      red[4 + wave] = dmax;
-                    __syncthreads();
-                    const double dinf = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
-                    if (dinf < 0.5)
-                      break;
-                    const int j = ord[r];
-                    if (tid < nn1)
-                      del = fma(tvec(tid, j), utg[j], del);
-                  }
-                if (tid < nn1)
-                  gam[cix(tid)] = del;
-              }
-          }
-        __syncthreads();
-        // ---- c = D gamma (LOD.cc:727-743 / 576-577)
-        for (int i = tid; i < nc; i += 256)
-          {
-            double acc = 0.0;
-            for (int j = 0; j < nc; ++j)
-              acc = fma(Ds[i * ldm + j], gam[j], acc);
-            cvec[i] = acc;
-          }
-        __syncthreads();
-        // ---- phi = X c, zero on the boundary (LOD.cc:745-750), l2-normalised (LOD.cc:752)
-        double ssq = 0.0;
-        for (int dof = tid; dof < ((A.diag & 1024) ? 0 : nf); dof += 256)
-          {
-            const int     node = dof / S, comp = dof - node * S;
-            const int     ix = node % npx, iy = node / npx;
-            const double *xr  = xrow(ix, iy, comp);
-            double        acc = 0.0;
-            if (xr)
-              for (int j = 0; j < nc; ++j)
-                acc = fma(xr[j], cvec[j], acc);
-            phis[dof] = acc;
-            ssq       = fma(acc, acc, ssq);
-          }
-        const double nrm = sqrt(block_sum(ssq));
-        double      *ob  = A.basis + d.out_off + (size_t)dsel * nf;
-        double      *op  = A.premult + d.out_off + (size_t)dsel * nf;
-        for (int dof = tid; dof < nf; dof += 256)
-          {
-            const double v = phis[dof] / nrm;
-            phis[dof]      = v;
-            ob[dof]        = v;
-          }
-        __syncthreads();
-        // ---- psi = A_semi phi: identity rows on id-0 dofs (LOD.cc:537-541,758-765)
-        for (int dof = tid; dof < ((A.diag & 2048) ? 0 : nf); dof += 256)
-          {
-            const int  node = dof / S, comp = dof - node * S;
-            const int  ix = node % npx, iy = node / npx;
-            const bool dom = (ix == 0 && (d.flags & 1)) || (ix == d.nx && (d.flags & 2)) ||
-                             (iy == 0 && (d.flags & 4)) || (iy == d.ny && (d.flags & 8));
-            double acc;
-            if (dom)
-              acc = phis[dof];
-            else
-              {
-                acc = 0.0;
-                for (int dy = -1; dy <= 1; ++dy)
-                  for (int dx = -1; dx <= 1; ++dx)
-                    {
-                      const int jx = ix + dx, jy = iy + dy;
-                      if (jx < 0 || jx > d.nx || jy < 0 || jy > d.ny)
-                        continue;
-                      const int dir = (dy + 1) * 3 + dx + 1;
-#pragma unroll
-                      for (int cb = 0; cb < S; ++cb)
-                        acc = fma(st[(size_t)((dir * S + comp) * S + cb) * A.nn_max + node],
-                                  phis[(jx + jy * npx) * S + cb], acc);
-                    }
-              }
-            op[dof] = acc;
-          }
-        __syncthreads();
-      }
+    select_patch<S>(A, nb_max, nf_max, blockIdx.x, smem);
   }
 } // namespace
 
@@ -630,8 +15,9 @@ size_t slod_select_lds_bytes(int /*S*/, int nb_max, int nc_max, int nf_max)
 {
   // must mirror the carve-up at the top of k_select
   const size_t bd = (size_t)nb_max * nc_max > (size_t)nf_max ? (size_t)nb_max * nc_max : (size_t)nf_max;
-  const size_t n  = (size_t)nc_max * (nc_max + 1) + (size_t)nc_max * nc_max + bd + 5 * (size_t)nc_max + 8;
-  return n * sizeof(double) + (3 * (size_t)nc_max + 4) * sizeof(int);
+  const size_t n  = (size_t)nc_max * (nc_max + 1) + (size_t)nc_max * nc_max + bd + 5 * (size_t)nc_max + 8 +
+                   2 * (size_t)nb_max;
+  return n * sizeof(double) + (5 * (size_t)nc_max + 4) * sizeof(int);
 }
 
 hipError_t slod_launch_select(int S, const SlodKernelArgs &a, int n_patches, int nb_max, int nf_max,

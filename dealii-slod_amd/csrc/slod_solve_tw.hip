@@ -1,5 +1,5 @@
 // k_solve_tw: twisted + wave-specialised patch solve (default).
-#include "slod_common.hip.h"
+#include "slod_select.hip.h"
 
 namespace
 {
@@ -54,6 +54,8 @@ namespace
     const int dl  = chain == 0 ? 1 : -1;
     auto      line_of = [&](int c, int t) { return c == 0 ? t : L - 1 - t; }; // t == n_c gives mid
 
+    if ((A.diag & (1 << 20)) && tid == 0)
+      A.ms[(size_t)blockIdx.x * A.nc_max * A.nc_max] = (double)wall_clock64();
     for (int idx = tid; idx < 2 * chsz; idx += 256)
       smem[idx] = 0.0;
     for (int c = tid; c < nc; c += 256)
@@ -525,6 +527,20 @@ namespace
           // the next iteration's first barrier orders the X and band writes before their readers
         }
     }
+    // Fused selection stage: the same workgroup goes on with M, D, the boundary trace, the
+    // least squares, phi and psi of its patch (X is fresh in this CU's L2 slice).  Patches of
+    // different shapes then balance inside ONE launch: rim patches are quick to solve and slow
+    // to select (SVD fallback), full patches the other way round.
+    const bool stamp = (A.diag & (1 << 20)) && tid == 0; // per-patch timeline (100 MHz clock) into ms
+    if (stamp)
+      A.ms[(size_t)blockIdx.x * A.nc_max * A.nc_max + 1] = (double)wall_clock64();
+    if (S == 1 && A.fuse_select)
+      {
+        __syncthreads(); // X of all lines is written; LDS is free
+        select_patch<S>(A, A.nb_buf, A.nf_max, blockIdx.x, smem);
+        if (stamp)
+          A.ms[(size_t)blockIdx.x * A.nc_max * A.nc_max + 2] = (double)wall_clock64();
+      }
   }
 
 } // namespace

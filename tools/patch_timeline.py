@@ -1,0 +1,61 @@
+# Timing experiment: per-patch timeline of the fused solve+select launch on C2 (SLOD_DIAG bit 20
+# makes thread 0 of every workgroup stamp the 100 MHz wall clock at start / after the solve /
+# after the selection stage).  Prints, per patch shape, start offset and the two durations.
+import ctypes as C
+import os
+import sys
+
+os.environ["SLOD_DIAG"] = str(1 << 20)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "dealii-slod_amd"))
+import numpy as np
+import torch
+import slod_amd
+from slod_amd.synthetic import fill_coefficient
+
+g = slod_amd.Slod(device=0, nref=5, n_sub=8, oversampling=2, spacedim=1, stabilize=1)
+dev = torch.device("cuda", 0)
+t = torch.from_numpy(fill_coefficient(20250614, "D1e4", g.NE)).to(dev)
+g.set_coefficient_device(0, t.data_ptr(), t.numel())
+ids = np.arange(g.num_patches, dtype=np.uint32)
+plan = g.plan(ids)
+basis = torch.zeros(len(ids) * plan.stride, dtype=torch.float64, device=dev)
+premult = torch.zeros_like(basis)
+for _ in range(3):
+    plan.execute(basis.data_ptr(), premult.data_ptr(), torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize()
+ncm = 25
+buf = np.zeros(len(ids) * ncm * ncm)
+lib = g.lib
+lib.slod_debug_read_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_size_t]
+assert lib.slod_debug_read_ms(plan.p, buf.ctypes.data_as(C.POINTER(C.c_double)), buf.size) == 0
+raw = buf.reshape(len(ids), ncm * ncm)[:, :12] / 100.0  # microseconds
+tt = raw[:, :3].copy()
+if not os.environ.get('SLOD_FUSE_SELECT', '1') != '0':
+    tt[:, 2] = raw[:, 11]
+t0 = tt[:, 0].min()
+shapes = {}
+for k, pid in enumerate(ids):
+    info = g.patch_layout(int(pid))
+    key = (min(info.mx, info.my), max(info.mx, info.my))
+    shapes.setdefault(key, []).append((tt[k, 0] - t0, tt[k, 1] - tt[k, 0], tt[k, 2] - tt[k, 1], tt[k, 2] - t0))
+print("launch span %.1f us" % (tt[:, 2].max() - t0))
+for key in sorted(shapes):
+    a = np.array(shapes[key])
+    print("shape %dx%d  n=%4d  start %6.1f..%6.1f  solve mean %6.1f max %6.1f  select mean %6.1f max %6.1f  end max %6.1f"
+          % (key[0], key[1], len(a), a[:, 0].min(), a[:, 0].max(), a[:, 1].mean(), a[:, 1].max(), a[:, 2].mean(),
+             a[:, 2].max(), a[:, 3].max()))
+full = np.array(shapes[(5, 5)])
+print("5x5 select histogram (us):", np.histogram(full[:, 2], bins=8))
+print("5x5 solve histogram (us):", np.histogram(full[:, 1], bins=8))
+
+# phases of the selection stage (full patches), fast path vs SVD fallback
+sel = [k for k, pid in enumerate(ids) if (lambda i: i.mx == 5 and i.my == 5)(g.patch_layout(int(pid)))]
+r = raw[sel]
+t_end_solve = r[:, 1]
+ph = dict(M=r[:, 3] - t_end_solve, D=r[:, 4] - r[:, 3], fill=r[:, 5], mult=r[:, 6], qr=r[:, 7],
+          rinv=r[:, 8] - r[:, 4] - r[:, 5] - r[:, 6] - r[:, 7], svd=r[:, 9] - r[:, 8], phi=r[:, 10] - r[:, 9],
+          psi=r[:, 11] - r[:, 10])
+slow = ph["svd"] > 20.0
+for name, m in (("fast path", ~slow), ("SVD fallback", slow)):
+    print("%-13s n=%3d " % (name, m.sum()) + "  ".join("%s %.1f" % (k, v[m].mean()) for k, v in ph.items()))
