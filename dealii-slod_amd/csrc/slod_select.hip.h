@@ -184,36 +184,90 @@ namespace
     stamp(3);
 
     // ---- D = M^{-1} (LOD.cc:553) by the symmetric sweep; M is SPD
-    for (int k = 0; k < ((A.diag & 128) ? 0 : nc); ++k)
+    if (nc * nc <= 1024)
       {
-        for (int j = tid; j < nc; j += 256)
-          rowk[j] = Ms[k * ldm + j];
+        // register-resident: every thread keeps its <= 4 entries and their (i,j); the pivot row is
+        // handed on through a double-buffered LDS line by the threads that own row k+1, so a pivot
+        // costs one barrier and no index arithmetic
+        double mv[4];
+        int    mi[4], mj[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          {
+            const int idx = tid + 256 * e;
+            mi[e]         = idx / nc;
+            mj[e]         = idx - mi[e] * nc;
+            mv[e]         = (idx < nc * nc) ? Ms[mi[e] * ldm + mj[e]] : 0.0;
+            if (idx < nc * nc && mi[e] == 0)
+              cvec[mj[e]] = mv[e];
+          }
         __syncthreads();
-        const double piv = rowk[k];
-        if (tid == 0 && !(piv > 0.0) && !A.diag)
-          atomicOr(A.status, 2);
-        const double p = fast_rcp(piv);
+        for (int k = 0; k < ((A.diag & 128) ? 0 : nc); ++k)
+          {
+            const double *rk  = (k & 1) ? rowk : cvec;
+            double       *rn  = (k & 1) ? cvec : rowk;
+            const double  piv = rk[k];
+            if (tid == 0 && !(piv > 0.0) && !A.diag)
+              atomicOr(A.status, 2);
+            const double p = fast_rcp(piv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (tid + 256 * e < nc * nc)
+                {
+                  const int    i = mi[e], j = mj[e];
+                  const double ri = rk[i], rj = rk[j];
+                  double       v;
+                  if (i == k)
+                    v = (j == k) ? -p : rj * p;
+                  else if (j == k)
+                    v = ri * p;
+                  else
+                    v = fma(-(ri * rj), p, mv[e]);
+                  mv[e] = v;
+                  if (i == k + 1)
+                    rn[j] = v;
+                }
+            __syncthreads();
+          }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (tid + 256 * e < nc * nc)
+            Ms[mi[e] * ldm + mj[e]] = -mv[e];
+        __syncthreads();
+      }
+    else
+      {
+        for (int k = 0; k < ((A.diag & 128) ? 0 : nc); ++k)
+          {
+            for (int j = tid; j < nc; j += 256)
+              rowk[j] = Ms[k * ldm + j];
+            __syncthreads();
+            const double piv = rowk[k];
+            if (tid == 0 && !(piv > 0.0) && !A.diag)
+              atomicOr(A.status, 2);
+            const double p = fast_rcp(piv);
+            for (int idx = tid; idx < nc * nc; idx += 256)
+              {
+                const int    i = idx / nc, j = idx - i * nc;
+                const double ri = rowk[i], rj = rowk[j];
+                double       v;
+                if (i == k)
+                  v = (j == k) ? -p : rj * p;
+                else if (j == k)
+                  v = ri * p;
+                else
+                  v = fma(-(ri * rj), p, Ms[i * ldm + j]);
+                Ms[i * ldm + j] = v;
+              }
+            __syncthreads();
+          }
         for (int idx = tid; idx < nc * nc; idx += 256)
           {
-            const int    i = idx / nc, j = idx - i * nc;
-            const double ri = rowk[i], rj = rowk[j];
-            double       v;
-            if (i == k)
-              v = (j == k) ? -p : rj * p;
-            else if (j == k)
-              v = ri * p;
-            else
-              v = fma(-(ri * rj), p, Ms[i * ldm + j]);
-            Ms[i * ldm + j] = v;
+            const int i = idx / nc, j = idx - i * nc;
+            Ms[i * ldm + j] = -Ms[i * ldm + j];
           }
         __syncthreads();
       }
-    for (int idx = tid; idx < nc * nc; idx += 256)
-      {
-        const int i = idx / nc, j = idx - i * nc;
-        Ms[i * ldm + j] = -Ms[i * ldm + j];
-      }
-    __syncthreads();
     stamp(4);
     double *Ds = Ms;
 
@@ -236,34 +290,58 @@ namespace
             for (int r0 = 0; r0 < nb;)
               {
                 const int take = min(nb - r0, nbuf - filled);
-                // stencil rows instead of the dense S_boundary
-                for (int idx = tid; idx < ((A.diag & 256) ? 0 : take * nc); idx += 256)
-                  {
-                    const int br = idx / nc, c = idx - br * nc;
-                    const int bi = r0 + br;
-                    const int bn = bi / S, ca = bi - bn * S;
-                    int       ix, iy;
-                    boundary_node(d, bn, ix, iy);
-                    double acc = -A.scale * ptw(ix, iy, ca, c);
+                // stencil rows instead of the dense S_boundary.  Lanes run along the columns of a
+                // row (coalesced X rows); the phase is bound by the latency of its load batches, so a
+                // thread works on U entries at once: U * 18 independent loads per batch
+                {
+                  constexpr int U = 1;
+                  for (int idx0 = tid; idx0 < ((A.diag & 256) ? 0 : take * nc); idx0 += 256 * U)
+                    {
+                      double sv[U][9][S], xv[U][9][S], acc[U];
+                      int    dst[U];
 #pragma unroll
-                    for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-                      for (int dx = -1; dx <= 1; ++dx)
+                      for (int u = 0; u < U; ++u)
                         {
-                          const int  jx = ix + dx, jy = iy + dy;
-                          const bool in = (jx > 0 && jx < d.nx && jy > 0 && jy < d.ny);
-                          const int  jxc = min(max(jx, 1), d.nx - 1), jyc = min(max(jy, 1), d.ny - 1);
-                          const int  dir = (dy + 1) * 3 + dx + 1;
-                          const int  l = tr ? jxc - 1 : jyc - 1, pos = tr ? jyc - 1 : jxc - 1;
+                          const int  idx = idx0 + 256 * u;
+                          const bool ok  = idx < take * nc;
+                          const int  br = ok ? idx / nc : 0, c = ok ? idx - br * nc : 0;
+                          const int  bi = r0 + br;
+                          const int  bn = bi / S, ca = bi - bn * S;
+                          int        ix, iy;
+                          boundary_node(d, bn, ix, iy);
+                          acc[u] = -A.scale * ptw(ix, iy, ca, c);
+                          dst[u] = ok ? (filled + br) * ncm + c : -1;
 #pragma unroll
-                          for (int cb = 0; cb < S; ++cb)
-                            {
-                              const double sv = in ? st[(size_t)((dir * S + ca) * S + cb) * A.nn_max + ix + iy * npx] : 0.0;
-                              acc = fma(sv, xg[(size_t)l * xline + (size_t)(pos * S + cb) * ncs + c], acc);
-                            }
+                          for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                            for (int dx = -1; dx <= 1; ++dx)
+                              {
+                                const int  jx = ix + dx, jy = iy + dy;
+                                const bool in = (jx > 0 && jx < d.nx && jy > 0 && jy < d.ny);
+                                const int  jxc = min(max(jx, 1), d.nx - 1), jyc = min(max(jy, 1), d.ny - 1);
+                                const int  dir = (dy + 1) * 3 + dx + 1;
+                                const int  l = tr ? jxc - 1 : jyc - 1, pos = tr ? jyc - 1 : jxc - 1;
+#pragma unroll
+                                for (int cb = 0; cb < S; ++cb)
+                                  {
+                                    sv[u][dir][cb] = in ? st[(size_t)((dir * S + ca) * S + cb) * A.nn_max + ix + iy * npx] : 0.0;
+                                    xv[u][dir][cb] = xg[(size_t)l * xline + (size_t)(pos * S + cb) * ncs + c];
+                                  }
+                              }
                         }
-                    BD[(filled + br) * ncm + c] = acc;
-                  }
+#pragma unroll
+                      for (int u = 0; u < U; ++u)
+                        {
+#pragma unroll
+                          for (int dir = 0; dir < 9; ++dir)
+#pragma unroll
+                            for (int cb = 0; cb < S; ++cb)
+                              acc[u] = fma(sv[u][dir][cb], xv[u][dir][cb], acc[u]);
+                          if (dst[u] >= 0)
+                            BD[dst[u]] = acc[u];
+                        }
+                    }
+                }
                 __syncthreads();
                 tacc(0);
                 // rows <- rows * D on the fp64 matrix pipe (v_mfma_f64_16x16x4_f64): a wave owns
@@ -732,74 +810,149 @@ namespace
                     fro            = fma(w, w, fro);
                   }
                 const double tiny = 1e-22 * block_sum(fro);
-                for (int sweep = 0; sweep < ((A.diag & 8192) ? 3 : 40); ++sweep)
+                if (nev / 2 <= 16 && (A.diag & 131072))
                   {
-                    if (tid == 0)
-                      flag[0] = 0;
-                    __syncthreads();
-                    for (int round = 0; round < nev - 1; ++round)
+                    // All nev/2 <= 16 column pairs of a round fit ONE wave (4 lanes per pair): wave 0
+                    // runs the sweeps alone, LDS accesses of one wave execute in order, so a round
+                    // needs no workgroup barrier at all (the round trip through four waves cost more
+                    // than the rotation arithmetic).
+                    if (wave == 0)
                       {
-                        for (int pr = grp; pr < nev / 2; pr += 16)
+                        const int l4 = lane & 3, pr = lane >> 2;
+                        for (int sweep = 0; sweep < ((A.diag & 8192) ? 3 : 40); ++sweep)
                           {
-                            int pa, pb;
-                            if (pr == 0)
+                            bool any = false;
+                            for (int round = 0; round < nev - 1; ++round)
                               {
-                                pa = nev - 1;
-                                pb = round;
+                                int pa, pb2;
+                                if (pr == 0)
+                                  {
+                                    pa  = nev - 1;
+                                    pb2 = round;
+                                  }
+                                else
+                                  {
+                                    pa  = round + pr;
+                                    pa  = pa >= nev - 1 ? pa - (nev - 1) : pa;
+                                    pb2 = round - pr;
+                                    pb2 = pb2 < 0 ? pb2 + (nev - 1) : pb2;
+                                  }
+                                const bool valid = pr < nev / 2 && pa < nn1 && pb2 < nn1;
+                                const int  p = valid ? (pa < pb2 ? pa : pb2) : 0, q = valid ? (pa < pb2 ? pb2 : pa) : 0;
+                                const int  cp = wcol(p), cq = wcol(q);
+                                double     app = 0, aqq = 0, apq = 0;
+                                for (int r = l4; r < wr; r += 4)
+                                  {
+                                    const double wp = Wm[r * ncm + cp], wq = Wm[r * ncm + cq];
+                                    app = fma(wp, wp, app);
+                                    aqq = fma(wq, wq, aqq);
+                                    apq = fma(wp, wq, apq);
+                                  }
+                                app += dpp_rot<0xB1>(app); // quad_perm [1,0,3,2]
+                                aqq += dpp_rot<0xB1>(aqq);
+                                apq += dpp_rot<0xB1>(apq);
+                                app += dpp_rot<0x4E>(app); // quad_perm [2,3,0,1]
+                                aqq += dpp_rot<0x4E>(aqq);
+                                apq += dpp_rot<0x4E>(apq);
+                                const bool rot = valid && !(apq == 0.0 || apq * apq <= 1e-30 * (app * aqq) ||
+                                                            fmin(app, aqq) <= tiny);
+                                if (rot)
+                                  {
+                                    const double dd = aqq - app;
+                                    const double hh = fma(dd, dd, 4.0 * apq * apq);
+                                    const double hy = hh * fast_rsqrt(hh); // sqrt(dd^2 + 4 apq^2)
+                                    const double t  = (dd >= 0.0 ? 2.0 : -2.0) * apq * fast_rcp(fabs(dd) + hy);
+                                    const double cs = fast_rsqrt(fma(t, t, 1.0)), sn = cs * t;
+                                    for (int r = l4; r < wr; r += 4)
+                                      {
+                                        const double wp = Wm[r * ncm + cp], wq = Wm[r * ncm + cq];
+                                        Wm[r * ncm + cp] = cs * wp - sn * wq;
+                                        Wm[r * ncm + cq] = sn * wp + cs * wq;
+                                      }
+                                    for (int r = l4; r < nn1; r += 4)
+                                      {
+                                        const double vp = Vj[r * nn1 + p], vq = Vj[r * nn1 + q];
+                                        Vj[r * nn1 + p] = cs * vp - sn * vq;
+                                        Vj[r * nn1 + q] = sn * vp + cs * vq;
+                                      }
+                                    any = true;
+                                  }
                               }
-                            else
-                              {
-                                pa = round + pr;
-                                pa = pa >= nev - 1 ? pa - (nev - 1) : pa;
-                                pb = round - pr;
-                                pb = pb < 0 ? pb + (nev - 1) : pb;
-                              }
-                            if (pa >= nn1 || pb >= nn1)
-                              continue;
-                            const int p = pa < pb ? pa : pb, q = pa < pb ? pb : pa;
-                            const int cp = wcol(p), cq = wcol(q);
-                            double    app = 0, aqq = 0, apq = 0;
-                            for (int r = l16; r < wr; r += 16)
-                              {
-                                const double wp = Wm[r * ncm + cp], wq = Wm[r * ncm + cq];
-                                app = fma(wp, wp, app);
-                                aqq = fma(wq, wq, aqq);
-                                apq = fma(wp, wq, apq);
-                              }
-                            app = group16_sum(app);
-                            aqq = group16_sum(aqq);
-                            apq = group16_sum(apq);
-                            if (apq == 0.0 || apq * apq <= 1e-30 * (app * aqq) || fmin(app, aqq) <= tiny)
-                              continue;
-                            // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (aqq-app)/(2 apq),
-                            // written without the division by apq; c = 1/sqrt(1+t^2), s = c t
-                            const double dd = aqq - app;
-                            const double hh = fma(dd, dd, 4.0 * apq * apq);
-                            const double hy = hh * fast_rsqrt(hh); // sqrt(dd^2 + 4 apq^2)
-                            const double t  = (dd >= 0.0 ? 2.0 : -2.0) * apq * fast_rcp(fabs(dd) + hy);
-                            const double cs = fast_rsqrt(fma(t, t, 1.0)), sn = cs * t;
-                            for (int r = l16; r < wr; r += 16)
-                              {
-                                const double wp = Wm[r * ncm + cp], wq = Wm[r * ncm + cq];
-                                Wm[r * ncm + cp] = cs * wp - sn * wq;
-                                Wm[r * ncm + cq] = sn * wp + cs * wq;
-                              }
-                            for (int r = l16; r < nn1; r += 16)
-                              {
-                                const double vp = Vj[r * nn1 + p], vq = Vj[r * nn1 + q];
-                                Vj[r * nn1 + p] = cs * vp - sn * vq;
-                                Vj[r * nn1 + q] = sn * vp + cs * vq;
-                              }
-                            if (l16 == 0)
-                              flag[0] = 1;
+                            if (!__any(any))
+                              break;
                           }
-                        __syncthreads();
                       }
-                    const int any = flag[0];
                     __syncthreads();
-                    if (!any)
-                      break;
                   }
+                else
+                  for (int sweep = 0; sweep < ((A.diag & 8192) ? 3 : 40); ++sweep)
+                    {
+                      if (tid == 0)
+                        flag[0] = 0;
+                      __syncthreads();
+                      for (int round = 0; round < nev - 1; ++round)
+                        {
+                          for (int pr = grp; pr < nev / 2; pr += 16)
+                            {
+                              int pa, pb;
+                              if (pr == 0)
+                                {
+                                  pa = nev - 1;
+                                  pb = round;
+                                }
+                              else
+                                {
+                                  pa = round + pr;
+                                  pa = pa >= nev - 1 ? pa - (nev - 1) : pa;
+                                  pb = round - pr;
+                                  pb = pb < 0 ? pb + (nev - 1) : pb;
+                                }
+                              if (pa >= nn1 || pb >= nn1)
+                                continue;
+                              const int p = pa < pb ? pa : pb, q = pa < pb ? pb : pa;
+                              const int cp = wcol(p), cq = wcol(q);
+                              double    app = 0, aqq = 0, apq = 0;
+                              for (int r = l16; r < wr; r += 16)
+                                {
+                                  const double wp = Wm[r * ncm + cp], wq = Wm[r * ncm + cq];
+                                  app = fma(wp, wp, app);
+                                  aqq = fma(wq, wq, aqq);
+                                  apq = fma(wp, wq, apq);
+                                }
+                              app = group16_sum(app);
+                              aqq = group16_sum(aqq);
+                              apq = group16_sum(apq);
+                              if (apq == 0.0 || apq * apq <= 1e-30 * (app * aqq) || fmin(app, aqq) <= tiny)
+                                continue;
+                              // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (aqq-app)/(2 apq),
+                              // written without the division by apq; c = 1/sqrt(1+t^2), s = c t
+                              const double dd = aqq - app;
+                              const double hh = fma(dd, dd, 4.0 * apq * apq);
+                              const double hy = hh * fast_rsqrt(hh); // sqrt(dd^2 + 4 apq^2)
+                              const double t  = (dd >= 0.0 ? 2.0 : -2.0) * apq * fast_rcp(fabs(dd) + hy);
+                              const double cs = fast_rsqrt(fma(t, t, 1.0)), sn = cs * t;
+                              for (int r = l16; r < wr; r += 16)
+                                {
+                                  const double wp = Wm[r * ncm + cp], wq = Wm[r * ncm + cq];
+                                  Wm[r * ncm + cp] = cs * wp - sn * wq;
+                                  Wm[r * ncm + cq] = sn * wp + cs * wq;
+                                }
+                              for (int r = l16; r < nn1; r += 16)
+                                {
+                                  const double vp = Vj[r * nn1 + p], vq = Vj[r * nn1 + q];
+                                  Vj[r * nn1 + p] = cs * vp - sn * vq;
+                                  Vj[r * nn1 + q] = sn * vp + cs * vq;
+                                }
+                              if (l16 == 0)
+                                flag[0] = 1;
+                            }
+                          __syncthreads();
+                        }
+                      const int any = flag[0];
+                      __syncthreads();
+                      if (!any)
+                        break;
+                    }
                 // sig_j = sigma_j(G); utg_j = coefficient of the j-th term's vector
                 for (int j = tid; j < nn1; j += 256)
                   {
@@ -821,26 +974,25 @@ namespace
                 __syncthreads();
                 // term vectors: V_j (no QR) or w_j (after the QR); element a2 of term j
                 auto tvec = [&](int a2, int j) { return tposed ? Wm[a2 * ncm + j] : Vj[a2 * nn1 + j]; };
-                if (tid == 0)
+                // descending sigma (stable: ties keep the column order), pseudo-inverse cutoff
+                // (LOD.cc:667): thread j ranks its own singular value
+                for (int j = tid; j < nn1; j += 256)
                   {
-                    // descending sigma, pseudo-inverse cutoff (LOD.cc:667)
-                    for (int j = 0; j < nn1; ++j)
-                      ord[j] = j;
-                    for (int a2 = 1; a2 < nn1; ++a2)
+                    const double sj = sig[j];
+                    int          rank = 0;
+                    for (int i = 0; i < nn1; ++i)
                       {
-                        const int o = ord[a2];
-                        int       b2 = a2 - 1;
-                        while (b2 >= 0 && sig[ord[b2]] < sig[o])
-                          {
-                            ord[b2 + 1] = ord[b2];
-                            --b2;
-                          }
-                        ord[b2 + 1] = o;
+                        const double si = sig[i];
+                        rank += (si > sj || (si == sj && i < j)) ? 1 : 0;
                       }
-                    const double s0 = sig[ord[0]];
-                    for (int j = 0; j < nn1; ++j)
-                      utg[j] = (sig[j] > 1e-15 * s0) ? utg[j] / sig[j] : 0.0;
+                    ord[rank] = j;
                   }
+                __syncthreads();
+                {
+                  const double s0 = sig[ord[0]];
+                  for (int j = tid; j < nn1; j += 256)
+                    utg[j] = (sig[j] > 1e-15 * s0) ? utg[j] / sig[j] : 0.0;
+                }
                 __syncthreads();
                 // d = -G^+ g (LOD.cc:669-671), one thread per component
                 double del = 0.0;
@@ -849,22 +1001,39 @@ namespace
                     del = fma(-tvec(tid, j), utg[j], del);
                 // the 0.5-loop (LOD.cc:703-725): put the smallest remaining triplet back while
                 // ||d||_inf >= 0.5 (the test precedes every removal)
-                for (int r = nn1 - 1; r >= 0; --r)
+                if (nn1 <= 64)
                   {
-                    double dmax = (tid < nn1) ? fabs(del) : 0.0;
-                    for (int off = 32; off > 0; off >>= 1)
-                      dmax = fmax(dmax, __shfl_xor(dmax, off, 64));
-                    __syncthreads();
-                    if (lane == 0)
-                      red[4 + wave] = dmax;
-                    __syncthreads();
-                    const double dinf = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
-                    if (dinf < 0.5)
-                      break;
-                    const int j = ord[r];
-                    if (tid < nn1)
-                      del = fma(tvec(tid, j), utg[j], del);
+                    // all components live in wave 0: no workgroup barrier per removal
+                    if (wave == 0)
+                      for (int r = nn1 - 1; r >= 0; --r)
+                        {
+                          double dmax = (tid < nn1) ? fabs(del) : 0.0;
+                          for (int off = 32; off > 0; off >>= 1)
+                            dmax = fmax(dmax, __shfl_xor(dmax, off, 64));
+                          if (dmax < 0.5)
+                            break;
+                          const int j = ord[r];
+                          if (tid < nn1)
+                            del = fma(tvec(tid, j), utg[j], del);
+                        }
                   }
+                else
+                  for (int r = nn1 - 1; r >= 0; --r)
+                    {
+                      double dmax = (tid < nn1) ? fabs(del) : 0.0;
+                      for (int off = 32; off > 0; off >>= 1)
+                        dmax = fmax(dmax, __shfl_xor(dmax, off, 64));
+                      __syncthreads();
+                      if (lane == 0)
+                        red[4 + wave] = dmax;
+                      __syncthreads();
+                      const double dinf = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+                      if (dinf < 0.5)
+                        break;
+                      const int j = ord[r];
+                      if (tid < nn1)
+                        del = fma(tvec(tid, j), utg[j], del);
+                    }
                 if (tid < nn1)
                   gam[cix(pc[tid])] = del; // component of the pc[tid]-th column of BD'
               }

@@ -18,6 +18,9 @@ dev = torch.device("cuda", 0)
 t = torch.from_numpy(fill_coefficient(20250614, "D1e4", g.NE)).to(dev)
 g.set_coefficient_device(0, t.data_ptr(), t.numel())
 ids = np.arange(g.num_patches, dtype=np.uint32)
+if len(sys.argv) > 1:  # only the first N full (5x5) patches: N = 256 gives one workgroup per CU
+    full = [int(i) for i in ids if g.patch_layout(int(i)).mx == 5 and g.patch_layout(int(i)).my == 5]
+    ids = np.array(full[:int(sys.argv[1])], dtype=np.uint32)
 plan = g.plan(ids)
 basis = torch.zeros(len(ids) * plan.stride, dtype=torch.float64, device=dev)
 premult = torch.zeros_like(basis)
