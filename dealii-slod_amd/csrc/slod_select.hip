@@ -16,7 +16,7 @@ size_t slod_select_lds_bytes(int /*S*/, int nb_max, int nc_max, int nf_max)
   // must mirror the carve-up at the top of k_select
   const size_t bd = (size_t)nb_max * nc_max > (size_t)nf_max ? (size_t)nb_max * nc_max : (size_t)nf_max;
   const size_t n  = (size_t)nc_max * (nc_max + 1) + (size_t)nc_max * nc_max + bd + 5 * (size_t)nc_max + 8 +
-                   2 * (size_t)nb_max;
+                   2 * (size_t)(nb_max > 160 ? nb_max : 160);
   return n * sizeof(double) + (5 * (size_t)nc_max + 4) * sizeof(int);
 }
 

@@ -42,8 +42,9 @@ namespace
     double *cvec = gam + ncm;
     double *rowk = cvec + ncm;           // [ncm]
     double *red  = rowk + ncm;           // [8]
-    double *vcol = red + 8;              // [2][nb_max] pivot column of the register-resident QR
-    int    *colk = reinterpret_cast<int *>(vcol + 2 * nb_max); // [2][ncm] cell of column
+    const int vst = max(nb_max, 160);
+    double *vcol = red + 8;              // [2][vst] pivot column of the register-resident QR
+    int    *colk = reinterpret_cast<int *>(vcol + 2 * vst); // [2][ncm] cell of column
     int    *ord  = colk + 2 * ncm;       // [ncm]
     int    *flag = ord + ncm;            // [4]
     int    *pcol = flag + 4;             // [2][ncm] column order of the pivoted second-stage QR
@@ -287,6 +288,97 @@ namespace
             int       nr   = 0;     // rows of the matrix the SVD fallback works on
             bool      need_svd = true, singular = false, did_qr = false;
             int       filled = 0;
+            // Householder sweep of a register-resident rows x [BD' | b0] block: the 16-lane group g
+            // holds logical columns g and g+16 (column j < nn1 is BD' column j, column nn1 is b0), lane
+            // l16 of it the rows l16 + 16 i.  Only the pivot column goes through LDS (double buffered,
+            // published together with its norm by the group that owns it one step ahead): one barrier
+            // and ~8 LDS operations per reflector and thread instead of ~60.
+            auto qr_sweep = [&](auto &a, const int rows, const bool last) __attribute__((always_inline)) {
+              constexpr int RQ = sizeof(a[0]) / sizeof(double);
+            if (grp == 0)
+              {
+                double nx0 = 0.0;
+#pragma unroll
+                for (int i = 0; i < RQ; ++i)
+                  {
+                    nx0 = fma(a[0][i], a[0][i], nx0);
+                    if (l16 + 16 * i < rows)
+                      vcol[l16 + 16 * i] = a[0][i];
+                  }
+                nx0 = group16_sum(nx0);
+                if (l16 == 0)
+                  sig[0] = nx0;
+              }
+            __syncthreads();
+            for (int k = 0; k < nn1; ++k)
+              {
+                const double *vc    = vcol + (k & 1) * vst;
+                double       *vn    = vcol + ((k + 1) & 1) * vst;
+                const double  sigma = sig[k & 1];
+                const bool    act   = sigma > 0.0;
+                if (!act && last)
+                  singular = true; // zero column (rank deficient): replayed through the SVD
+                const double x0    = vc[k];
+                const double sq    = act ? sigma * fast_rsqrt(sigma) : 0.0;
+                const double alpha = (x0 >= 0.0) ? -sq : sq;
+                const double v0    = x0 - alpha;
+                const double beta  = act ? fast_rcp(sigma - alpha * x0) : 0.0; // 2 / v^T v
+                double       vr[RQ];
+#pragma unroll
+                for (int i = 0; i < RQ; ++i)
+                  {
+                    const int r = l16 + 16 * i;
+                    vr[i]       = (r == k) ? v0 : ((r > k && r < rows) ? vc[r] : 0.0);
+                  }
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl)
+                  {
+                    const int j = grp + 16 * sl;
+                    if (j == k)
+                      {
+                        // this column is finished: R_kk on the diagonal, zeros below
+#pragma unroll
+                        for (int i = 0; i < RQ; ++i)
+                          {
+                            const int r = l16 + 16 * i;
+                            a[sl][i]    = (r == k) ? (act ? alpha : a[sl][i]) : (r > k ? 0.0 : a[sl][i]);
+                          }
+                      }
+                    else if (j > k && j <= nn1)
+                      {
+                        double sd = 0.0;
+#pragma unroll
+                        for (int i = 0; i < RQ; ++i)
+                          sd = fma(vr[i], a[sl][i], sd);
+                        sd = group16_sum(sd) * beta;
+#pragma unroll
+                        for (int i = 0; i < RQ; ++i)
+                          a[sl][i] = fma(-sd, vr[i], a[sl][i]);
+                        if (j == k + 1 && j < nn1) // the next pivot column: publish it
+                          {
+                            double nxt = 0.0;
+#pragma unroll
+                            for (int i = 0; i < RQ; ++i)
+                              {
+                                const int r = l16 + 16 * i;
+                                if (r > k)
+                                  nxt = fma(a[sl][i], a[sl][i], nxt);
+                                if (r < rows)
+                                  vn[r] = a[sl][i];
+                              }
+                            nxt = group16_sum(nxt);
+                            if (l16 == 0)
+                              sig[(k + 1) & 1] = nxt;
+                          }
+                      }
+                  }
+                __syncthreads();
+              }
+            };
+            // one pass over all boundary rows when they fit the registers (<= 160 rows): the row chunks
+            // only stage BD through LDS (fill, * D), a single sweep of nn1 reflectors follows
+            const bool onepass = nb <= 160 && nb > 96 && nc <= 32 && (nbuf & 15) == 0 && !(A.diag & (512 | 262144));
+            double     aq[2][10];
             for (int r0 = 0; r0 < nb;)
               {
                 const int take = min(nb - r0, nbuf - filled);
@@ -380,6 +472,26 @@ namespace
                   }
                 __syncthreads();
                 tacc(1);
+                if (onepass)
+                  {
+#pragma unroll
+                    for (int sl = 0; sl < 2; ++sl)
+                      {
+                        const int j = grp + 16 * sl, cj = j < nn1 ? cix(j) : dsel;
+#pragma unroll
+                        for (int i = 0; i < 10; ++i)
+                          {
+                            const int r = l16 + 16 * i;
+                            if (r >= r0 && r < r0 + take)
+                              aq[sl][i] = (j <= nn1) ? BD[(r - r0) * ncm + cj] : 0.0;
+                            else if (r0 == 0)
+                              aq[sl][i] = 0.0;
+                          }
+                      }
+                    r0 += take;
+                    __syncthreads(); // the next chunk overwrites the staging rows
+                    continue;
+                  }
                 r0 += take;
                 const int rows = filled + take;
                 nr             = rows;
@@ -412,85 +524,7 @@ namespace
                             a[sl][i]    = (j <= nn1 && r < rows) ? BD[r * ncm + cj] : 0.0;
                           }
                       }
-                    if (grp == 0)
-                      {
-                        double nx0 = 0.0;
-#pragma unroll
-                        for (int i = 0; i < 6; ++i)
-                          {
-                            nx0 = fma(a[0][i], a[0][i], nx0);
-                            if (l16 + 16 * i < rows)
-                              vcol[l16 + 16 * i] = a[0][i];
-                          }
-                        nx0 = group16_sum(nx0);
-                        if (l16 == 0)
-                          sig[0] = nx0;
-                      }
-                    __syncthreads();
-                    for (int k = 0; k < nn1; ++k)
-                      {
-                        const double *vc    = vcol + (k & 1) * nb_max;
-                        double       *vn    = vcol + ((k + 1) & 1) * nb_max;
-                        const double  sigma = sig[k & 1];
-                        const bool    act   = sigma > 0.0;
-                        if (!act && r0 >= nb)
-                          singular = true; // zero column (rank deficient): replayed through the SVD
-                        const double x0    = vc[k];
-                        const double sq    = act ? sigma * fast_rsqrt(sigma) : 0.0;
-                        const double alpha = (x0 >= 0.0) ? -sq : sq;
-                        const double v0    = x0 - alpha;
-                        const double beta  = act ? fast_rcp(sigma - alpha * x0) : 0.0; // 2 / v^T v
-                        double       vr[6];
-#pragma unroll
-                        for (int i = 0; i < 6; ++i)
-                          {
-                            const int r = l16 + 16 * i;
-                            vr[i]       = (r == k) ? v0 : ((r > k && r < rows) ? vc[r] : 0.0);
-                          }
-#pragma unroll
-                        for (int sl = 0; sl < 2; ++sl)
-                          {
-                            const int j = grp + 16 * sl;
-                            if (j == k)
-                              {
-                                // this column is finished: R_kk on the diagonal, zeros below
-#pragma unroll
-                                for (int i = 0; i < 6; ++i)
-                                  {
-                                    const int r = l16 + 16 * i;
-                                    a[sl][i]    = (r == k) ? (act ? alpha : a[sl][i]) : (r > k ? 0.0 : a[sl][i]);
-                                  }
-                              }
-                            else if (j > k && j <= nn1)
-                              {
-                                double sd = 0.0;
-#pragma unroll
-                                for (int i = 0; i < 6; ++i)
-                                  sd = fma(vr[i], a[sl][i], sd);
-                                sd = group16_sum(sd) * beta;
-#pragma unroll
-                                for (int i = 0; i < 6; ++i)
-                                  a[sl][i] = fma(-sd, vr[i], a[sl][i]);
-                                if (j == k + 1 && j < nn1) // the next pivot column: publish it
-                                  {
-                                    double nxt = 0.0;
-#pragma unroll
-                                    for (int i = 0; i < 6; ++i)
-                                      {
-                                        const int r = l16 + 16 * i;
-                                        if (r > k)
-                                          nxt = fma(a[sl][i], a[sl][i], nxt);
-                                        if (r < rows)
-                                          vn[r] = a[sl][i];
-                                      }
-                                    nxt = group16_sum(nxt);
-                                    if (l16 == 0)
-                                      sig[(k + 1) & 1] = nxt;
-                                  }
-                              }
-                          }
-                        __syncthreads();
-                      }
+                    qr_sweep(a, rows, r0 >= nb);
                     // back to LDS: R in the top nn1 rows (zero below the diagonal), zero rows below
 #pragma unroll
                     for (int sl = 0; sl < 2; ++sl)
@@ -599,6 +633,26 @@ namespace
                 filled = nn1;
                 nr     = nn1;
               }
+            if (onepass)
+              {
+                did_qr = true;
+                qr_sweep(aq, nb, true);
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl)
+                  {
+                    const int j = grp + 16 * sl, cj = j < nn1 ? cix(j) : dsel;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                      {
+                        const int r = l16 + 16 * i;
+                        if (j <= nn1 && r < nn1)
+                          BD[r * ncm + cj] = aq[sl][i];
+                      }
+                  }
+                __syncthreads();
+                tacc(2);
+                nr = nn1;
+              }
             if (did_qr && !(A.diag & 512))
               {
                 if (!singular)
@@ -664,7 +718,7 @@ namespace
                 // sigma_j(G) = |w_j|^2, u_j^T g = sigma_j (J_j . c), and the reference's term
                 // v_j (u_j^T g) / sigma_j(G) = w_j (J_j . c) / |w_j|^2.  Without a QR (fewer rows
                 // than columns) the sweeps run on BD' itself: W = BD' V, term = V_j (w_j . b0)/|w_j|^2.
-                const bool tposed = did_qr && nbuf >= 2 * nn1;
+                const bool tposed = did_qr && nbuf >= 2 * nn1 + 1;
                 double    *Wm     = BD;              // matrix whose columns are rotated
                 int        wr     = nr;              // its rows
                 int        pb     = 0;               // current buffer of the column order pcol
@@ -793,8 +847,14 @@ namespace
                         const int i = idx / nn1, j = idx - i * nn1;       // L[i][j] = R'[j][i]
                         Wm[i * ncm + j] = (j <= i) ? BD[j * ncm + cix(pc[i])] : 0.0;
                       }
+                    // c'^T rides along as an extra row: it takes every rotation (c'^T J, whose j-th
+                    // entry is J_j . c') but stays out of the dot products, so the rotations need
+                    // not be accumulated in a second matrix
+                    for (int j = tid; j < nn1; j += 256)
+                      Wm[nn1 * ncm + j] = BD[j * ncm + dsel];
                     wr = nn1;
                   }
+                const int wru = tposed ? wr + 1 : wr; // rows that take the rotations
                 auto wcol = [&](int j) { return tposed ? j : cix(j); };
                 const int nev = (nn1 + 1) & ~1;
                 for (int idx = tid; idx < nn1 * nn1; idx += 256)
@@ -863,13 +923,13 @@ namespace
                                     const double hy = hh * fast_rsqrt(hh); // sqrt(dd^2 + 4 apq^2)
                                     const double t  = (dd >= 0.0 ? 2.0 : -2.0) * apq * fast_rcp(fabs(dd) + hy);
                                     const double cs = fast_rsqrt(fma(t, t, 1.0)), sn = cs * t;
-                                    for (int r = l4; r < wr; r += 4)
+                                    for (int r = l4; r < wru; r += 4)
                                       {
                                         const double wp = Wm[r * ncm + cp], wq = Wm[r * ncm + cq];
                                         Wm[r * ncm + cp] = cs * wp - sn * wq;
                                         Wm[r * ncm + cq] = sn * wp + cs * wq;
                                       }
-                                    for (int r = l4; r < nn1; r += 4)
+                                    for (int r = l4; r < (tposed ? 0 : nn1); r += 4)
                                       {
                                         const double vp = Vj[r * nn1 + p], vq = Vj[r * nn1 + q];
                                         Vj[r * nn1 + p] = cs * vp - sn * vq;
@@ -931,13 +991,13 @@ namespace
                               const double hy = hh * fast_rsqrt(hh); // sqrt(dd^2 + 4 apq^2)
                               const double t  = (dd >= 0.0 ? 2.0 : -2.0) * apq * fast_rcp(fabs(dd) + hy);
                               const double cs = fast_rsqrt(fma(t, t, 1.0)), sn = cs * t;
-                              for (int r = l16; r < wr; r += 16)
+                              for (int r = l16; r < wru; r += 16)
                                 {
                                   const double wp = Wm[r * ncm + cp], wq = Wm[r * ncm + cq];
                                   Wm[r * ncm + cp] = cs * wp - sn * wq;
                                   Wm[r * ncm + cq] = sn * wp + cs * wq;
                                 }
-                              for (int r = l16; r < nn1; r += 16)
+                              for (int r = l16; r < (tposed ? 0 : nn1); r += 16)
                                 {
                                   const double vp = Vj[r * nn1 + p], vq = Vj[r * nn1 + q];
                                   Vj[r * nn1 + p] = cs * vp - sn * vq;
@@ -966,8 +1026,7 @@ namespace
                           wb = fma(w, BD[r * ncm + dsel], wb);           // w_j . b0
                       }
                     if (tposed)
-                      for (int i = 0; i < nn1; ++i)
-                        wb = fma(Vj[i * nn1 + j], BD[i * ncm + dsel], wb); // J_j . c
+                      wb = Wm[nn1 * ncm + j]; // (c'^T J)_j = J_j . c'
                     sig[j] = ss;
                     utg[j] = wb;
                   }
