@@ -657,26 +657,35 @@ namespace
               {
                 if (!singular)
                   {
-                    // R^{-1} by columns (thread j solves R x = e_j), Frobenius norms, d = -R^{-1} c
-                    double fr = 0.0, fi = 0.0;
-                    if (tid < nn1)
+                    // R^{-1} by columns, Frobenius norms, d = -R^{-1} c.  An 8-lane group solves
+                    // R x = e_j: the dot product of a back-substitution step is spread over the
+                    // lanes (3 DPP steps), x goes through LDS (one wave: in order), so a column
+                    // costs j short steps instead of j^2/2 dependent LDS round trips of one thread
+                    double    fr = 0.0, fi = 0.0;
+                    const int l8 = tid & 7;
+                    for (int j = tid >> 3; j < nn1; j += 32)
                       {
-                        const int j = tid;
-                        for (int i = 0; i <= j; ++i)
-                          {
-                            const double r = BD[i * ncm + cix(j)];
-                            fr             = fma(r, r, fr);
-                          }
-                        Vj[j * nn1 + j] = 1.0 / BD[j * ncm + cix(j)];
+                        const int cj = cix(j);
+                        if (l8 == 0)
+                          Vj[j * nn1 + j] = 1.0 / BD[j * ncm + cj];
                         for (int i = j - 1; i >= 0; --i)
                           {
-                            double s = 0.0;
-                            for (int k2 = i + 1; k2 <= j; ++k2)
-                              s = fma(BD[i * ncm + cix(k2)], Vj[k2 * nn1 + j], s);
-                            Vj[i * nn1 + j] = -s / BD[i * ncm + cix(i)];
+                            const double rd = fast_rcp(BD[i * ncm + cix(i)]);
+                            double       sa = 0.0;
+                            for (int k2 = i + 1 + l8; k2 <= j; k2 += 8)
+                              sa = fma(BD[i * ncm + cix(k2)], Vj[k2 * nn1 + j], sa);
+                            sa += dpp_rot<0xB1>(sa);  // quad_perm [1,0,3,2]
+                            sa += dpp_rot<0x4E>(sa);  // quad_perm [2,3,0,1]
+                            sa += dpp_rot<0x141>(sa); // row_half_mirror: the other quad of the 8 lanes
+                            if (l8 == 0)
+                              Vj[i * nn1 + j] = -sa * rd;
                           }
-                        for (int i = 0; i <= j; ++i)
-                          fi = fma(Vj[i * nn1 + j], Vj[i * nn1 + j], fi);
+                        for (int i = l8; i <= j; i += 8)
+                          {
+                            const double r = BD[i * ncm + cj], x = Vj[i * nn1 + j];
+                            fr             = fma(r, r, fr);
+                            fi             = fma(x, x, fi);
+                          }
                       }
                     const double nr2 = block_sum(fr), ni2 = block_sum(fi);
                     double       del = 0.0;
