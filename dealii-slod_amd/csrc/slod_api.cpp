@@ -509,7 +509,6 @@ int slod_plan_create(slod_handle *h, const uint32_t *gids, size_t n, const uint6
       delete p;
       return fail(h, SLOD_ERR_UNSUPPORTED, "slod_plan_create: more than 64 coarse dofs per patch");
     }
-  hipError_t e = hipSuccess;
   (void)nb_min_slod;
   // k_select reduces the boundary-trace matrix by QR in row chunks (TSQR): the LDS buffer
   // holds nb_buf rows, at least nc_max + 16 so every chunk brings new rows

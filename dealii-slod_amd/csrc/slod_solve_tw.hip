@@ -38,7 +38,7 @@ namespace
     double *Tn1  = Tn0 + bsz;
     double *Bc0  = Tn1 + bsz;        //   coupling bands of the steps (by step mod 3)
     double *Bc1  = Bc0 + bsz;
-    double *Bc2  = Bc1 + bsz;
+    // (third coupling buffer: Bc1 + bsz, addressed through Bbuf)
     auto    Bbuf = [&](double *base, int stp) { return base + ((stp + 3) % 3) * bsz; };
     double *ocb  = smem + (1 - chain) * chsz; // the other chain's block
     int    *colk = reinterpret_cast<int *>(smem + 2 * chsz); // [2][nc_max]
