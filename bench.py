@@ -237,7 +237,7 @@ def main():
                                    "(ensemble of %d realisations, contiguous patch blocks)"
                                    % (args.dist, hi / lo, n_local, world),
                        "patches_per_gpu": n_local, "parallelism": "patch-sharded x%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "k_solve_tw<5,1>" + (" (selection stage fused in)" if ks[2] < 0.05 * ks[1] else ""),
+            "roofline": {"bound": "mfma", "kernel": "k_solve_tw<5,1>" + (" (stencil assembly and selection stage fused in)" if ks[2] < 0.05 * ks[1] and ks[0] < 0.05 * ks[1] else (" (selection stage fused in)" if ks[2] < 0.05 * ks[1] else "")),
                          "achieved": achieved_tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / PEAK_FP64_TFLOPS, "traffic": traffic,
                          "algorithmic_flops_per_launch": flops,

@@ -246,6 +246,7 @@ namespace
     a.nb_buf    = p->nb_buf;
     a.nf_max    = p->nf_max;
     a.fuse_select = 0; // set by slod_launch_solve
+    a.fuse_assemble = 0;
     a.basis     = d_basis;
     a.premult   = d_premult;
     a.status    = p->d_status;
@@ -608,7 +609,8 @@ int slod_plan_execute(slod_plan *p, double *d_basis, double *d_premult, void *hi
       SlodKernelArgs       a   = make_args(p, first, d_basis, d_premult);
       hipEvent_t          *ev  = &p->ev[4 * ((p->n_exec % (size_t)p->depth) * p->n_chunks + ci)];
       e = hipEventRecord(ev[0], st);
-      if (e == hipSuccess)
+      a.fuse_assemble = slod_solve_fuses_assemble(s, a) ? 1 : 0;
+      if (e == hipSuccess && !a.fuse_assemble)
         e = slod_launch_assemble(s, a, cnt, st);
       if (e == hipSuccess)
         e = hipEventRecord(ev[1], st);

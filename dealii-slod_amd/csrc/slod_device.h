@@ -56,6 +56,7 @@ struct SlodKernelArgs
   int32_t nb_buf;   // rows of the selection stage's boundary-trace buffer
   int32_t nf_max;   // largest n_fine of the plan
   int32_t fuse_select; // set by slod_launch_solve: the solve kernel also ran the selection stage
+  int32_t fuse_assemble; // the solve kernel assembles the stencil of its own patch first
   // outputs
   double  *basis;
   double  *premult;
@@ -65,6 +66,7 @@ struct SlodKernelArgs
 // launchers (slod_assemble.hip, slod_solve_{tw,ws,coop}.hip, slod_select.hip)
 hipError_t slod_launch_assemble(int S, const SlodKernelArgs &a, int n_patches, hipStream_t st);
 hipError_t slod_launch_solve(int S, SlodKernelArgs &a, int n_patches, hipStream_t st); // slod_dispatch.cpp
+bool       slod_solve_fuses_assemble(int S, const SlodKernelArgs &a);               // slod_dispatch.cpp
 hipError_t slod_launch_solve_tw(int S, const SlodKernelArgs &a, int n_patches, size_t lds, hipStream_t st);
 hipError_t slod_launch_solve_ws(int S, const SlodKernelArgs &a, int n_patches, size_t lds, hipStream_t st);
 hipError_t slod_launch_solve_coop(int S, int twisted, const SlodKernelArgs &a, int n_patches, hipStream_t st);

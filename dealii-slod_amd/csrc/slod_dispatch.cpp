@@ -4,6 +4,17 @@
 #include <cstdlib>
 #include <cstring>
 
+// true when slod_launch_solve will pick k_solve_tw for a scalar problem: that kernel then assembles
+// the stencil itself (SLOD_FUSE_ASSEMBLE=0 keeps the separate k_assemble launch)
+bool slod_solve_fuses_assemble(int S, const SlodKernelArgs &a)
+{
+  const char *sel = getenv("SLOD_SOLVE");
+  const char *fa  = getenv("SLOD_FUSE_ASSEMBLE");
+  const bool  fits = slod_solve_ws_tile(a.m_max) >= 2 * S - 1 && slod_solve_ws_tile(a.m_max) > 0;
+  return S == 1 && !(fa && !atoi(fa)) && fits && (!sel || !strcmp(sel, "tw")) &&
+         slod_solve_tw_lds_bytes(S, a.m_max, a.nc_max) <= 160 * 1024;
+}
+
 hipError_t slod_launch_solve(int S, SlodKernelArgs &a, int n_patches, hipStream_t st)
 {
   a.m_fused = 0;

@@ -1,4 +1,5 @@
 // k_solve_tw: twisted + wave-specialised patch solve (default).
+#include "slod_assemble.hip.h"
 #include "slod_select.hip.h"
 
 namespace
@@ -56,6 +57,15 @@ namespace
 
     if ((A.diag & (1 << 20)) && tid == 0)
       A.ms[(size_t)blockIdx.x * A.nc_max * A.nc_max] = (double)wall_clock64();
+    // Fused stencil assembly: the workgroup builds the stencil planes of its own patch (k_assemble
+    // as a device function), saving a launch and its tail; the planes still go through the
+    // workspace, which the band fetches and the selection stage read back
+    if (S == 1 && A.fuse_assemble)
+      {
+        for (int node = tid; node < npx * (d.ny + 1); node += 256)
+          assemble_node<S>(A, d, blockIdx.x, node);
+        __syncthreads();
+      }
     for (int idx = tid; idx < 2 * chsz; idx += 256)
       smem[idx] = 0.0;
     for (int c = tid; c < nc; c += 256)
