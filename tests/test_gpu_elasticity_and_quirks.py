@@ -252,3 +252,7 @@ def test_fused_and_split_selection_agree(so, monkeypatch):
     monkeypatch.setenv("SLOD_FUSE_SELECT", "0")
     b0, p0, _ = g.compute_basis(ids)
     assert np.array_equal(b0, b1) and np.array_equal(p0, p1)
+    # same for the stencil assembly: SLOD_FUSE_ASSEMBLE=0 launches k_assemble on its own
+    monkeypatch.setenv("SLOD_FUSE_ASSEMBLE", "0")
+    b2, p2, _ = g.compute_basis(ids)
+    assert np.array_equal(b2, b1) and np.array_equal(p2, p1)
