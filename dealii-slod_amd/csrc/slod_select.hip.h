@@ -118,9 +118,18 @@ namespace
         for (int idx = tid; idx < nc * nc; idx += 256)
           Ms[(idx / nc) * ldm + (idx % nc)] = mg[idx];
       }
-    for (int idx = tid; idx < ((A.diag & 64) || A.m_fused ? 0 : nc * nc); idx += 256)
+    // M = P^T A^-1 P is symmetric and the sweep below treats it as such (column k is taken from
+    // row k), so only the entries a <= b are computed (half the load batches) and mirrored
+    for (int idx = tid; idx < ((A.diag & 64) || A.m_fused ? 0 : nc * (nc + 1) / 2); idx += 256)
       {
-        const int a = idx / nc, b = idx - a * nc;
+        // row a of the upper triangle holds nc - a entries: a = largest a with a (2 nc - a + 1) / 2 <= idx
+        int a = (int)((2.0f * nc + 1.0f - sqrtf((2.0f * nc + 1.0f) * (2.0f * nc + 1.0f) - 8.0f * idx)) * 0.5f);
+        a     = min(max(a, 0), nc - 1);
+        while (a > 0 && a * (2 * nc - a + 1) / 2 > idx)
+          --a;
+        while (a + 1 < nc && (a + 1) * (2 * nc - a) / 2 <= idx)
+          ++a;
+        const int b  = a + idx - a * (2 * nc - a + 1) / 2;
         const int kx = colk[a], ky = colk[ncm + a];
         double    acc = 0.0;
         if (S == 1 || !A.quirk)
@@ -180,6 +189,7 @@ namespace
                 }
           }
         Ms[a * ldm + b] = acc * A.scale * A.invH2;
+        Ms[b * ldm + a] = acc * A.scale * A.invH2;
       }
     __syncthreads();
     stamp(3);
