@@ -392,14 +392,16 @@ namespace
             for (int r0 = 0; r0 < nb;)
               {
                 const int take = min(nb - r0, nbuf - filled);
-                // stencil rows instead of the dense S_boundary.  Lanes run along the columns of a
-                // row (coalesced X rows); the phase is bound by the latency of its load batches, so a
-                // thread works on U entries at once: U * 18 independent loads per batch
+                // stencil rows instead of the dense S_boundary.  A boundary node has at most three
+                // interior neighbours: the ones one step along the inward normal (the other six
+                // couplings of its stencil row multiply X_B = 0), so an entry costs 3 stencil + 3 X
+                // loads; the phase is bound by the latency of its dependent load batches, so a thread
+                // works on U entries at once.  Lanes run along the columns of a row (coalesced X rows).
                 {
-                  constexpr int U = 1;
+                  constexpr int U = 2;
                   for (int idx0 = tid; idx0 < ((A.diag & 256) ? 0 : take * nc); idx0 += 256 * U)
                     {
-                      double sv[U][9][S], xv[U][9][S], acc[U];
+                      double sv[U][3][S], xv[U][3][S], acc[U];
                       int    dst[U];
 #pragma unroll
                       for (int u = 0; u < U; ++u)
@@ -413,32 +415,35 @@ namespace
                           boundary_node(d, bn, ix, iy);
                           acc[u] = -A.scale * ptw(ix, iy, ca, c);
                           dst[u] = ok ? (filled + br) * ncm + c : -1;
+                          const bool hor = (iy == 0 || iy == d.ny); // bottom / top row: neighbours along x
+                          const int  ndx = ix == 0 ? 1 : -1, ndy = iy == 0 ? 1 : -1;
 #pragma unroll
-                          for (int dy = -1; dy <= 1; ++dy)
+                          for (int e = -1; e <= 1; ++e)
+                            {
+                              const int  dx = hor ? e : ndx, dy = hor ? ndy : e;
+                              const int  jx = ix + dx, jy = iy + dy;
+                              const bool in = (jx > 0 && jx < d.nx && jy > 0 && jy < d.ny);
+                              const int  jxc = min(max(jx, 1), d.nx - 1), jyc = min(max(jy, 1), d.ny - 1);
+                              const int  dir = (dy + 1) * 3 + dx + 1;
+                              const int  l = tr ? jxc - 1 : jyc - 1, pos = tr ? jyc - 1 : jxc - 1;
 #pragma unroll
-                            for (int dx = -1; dx <= 1; ++dx)
-                              {
-                                const int  jx = ix + dx, jy = iy + dy;
-                                const bool in = (jx > 0 && jx < d.nx && jy > 0 && jy < d.ny);
-                                const int  jxc = min(max(jx, 1), d.nx - 1), jyc = min(max(jy, 1), d.ny - 1);
-                                const int  dir = (dy + 1) * 3 + dx + 1;
-                                const int  l = tr ? jxc - 1 : jyc - 1, pos = tr ? jyc - 1 : jxc - 1;
-#pragma unroll
-                                for (int cb = 0; cb < S; ++cb)
-                                  {
-                                    sv[u][dir][cb] = in ? st[(size_t)((dir * S + ca) * S + cb) * A.nn_max + ix + iy * npx] : 0.0;
-                                    xv[u][dir][cb] = xg[(size_t)l * xline + (size_t)(pos * S + cb) * ncs + c];
-                                  }
-                              }
+                              for (int cb = 0; cb < S; ++cb)
+                                {
+                                  // unconditional loads + select (a predicated load costs a branch)
+                                  const double svv = st[(size_t)((dir * S + ca) * S + cb) * A.nn_max + ix + iy * npx];
+                                  sv[u][e + 1][cb] = in ? svv : 0.0;
+                                  xv[u][e + 1][cb] = xg[(size_t)l * xline + (size_t)(pos * S + cb) * ncs + c];
+                                }
+                            }
                         }
 #pragma unroll
                       for (int u = 0; u < U; ++u)
                         {
 #pragma unroll
-                          for (int dir = 0; dir < 9; ++dir)
+                          for (int e = 0; e < 3; ++e)
 #pragma unroll
                             for (int cb = 0; cb < S; ++cb)
-                              acc[u] = fma(sv[u][dir][cb], xv[u][dir][cb], acc[u]);
+                              acc[u] = fma(sv[u][e][cb], xv[u][e][cb], acc[u]);
                           if (dst[u] >= 0)
                             BD[dst[u]] = acc[u];
                         }
