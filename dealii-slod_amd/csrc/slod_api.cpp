@@ -1,7 +1,10 @@
 // Host side of libslod_hip.so: handle / plan management, patch index calculus, launches.
 // Implements include/slod.h.  No CPU fallback exists: every compute entry point needs a
 // HIP device and fails with SLOD_ERR_DEVICE otherwise.
+// only the C-ABI of include/slod.h is exported (the library is built with -fvisibility=hidden)
+#pragma GCC visibility push(default)
 #include "../../include/slod.h"
+#pragma GCC visibility pop
 #include "slod_device.h"
 
 #include <algorithm>
@@ -33,6 +36,7 @@ struct slod_handle
   double             *d_coef[2]  = {nullptr, nullptr};
   std::vector<char>   coef_set;  // [problem*2 + field]
   hipStream_t         stream = nullptr;
+  bool                device_ready = false; // stream and coefficient storage exist
   mutable std::string error;
 };
 
@@ -49,6 +53,8 @@ struct slod_plan
   double                    *ws_st = nullptr, *ws_v = nullptr, *ws_x = nullptr, *ws_m = nullptr;
   size_t                     st_stride = 0, v_stride = 0, x_stride = 0;
   int32_t                   *d_status = nullptr;
+  SlodPatchDiag             *d_pdiag  = nullptr; // [n][spacedim] decisions of the selection stage
+  SlodSolveChoice            choice;             // kernel chosen at plan creation (slod_dispatch.cpp)
   std::vector<hipEvent_t>    ev; // [depth][n_chunks][4]
   size_t                     n_chunks = 0;
   int                        depth = 1; // event slots (slod_plan_profile)
@@ -194,24 +200,32 @@ namespace
   // stream + coefficient storage; called by every entry point that touches the device
   int ensure_device(slod_handle *h)
   {
-    if (h->stream)
+    if (h->device_ready)
       return SLOD_OK;
     hipError_t e = hipSetDevice(h->cfg.device);
     if (e != hipSuccess)
       return hip_fail(h, e, "hipSetDevice (no usable HIP device; this library has no CPU fallback)");
-    e = hipStreamCreate(&h->stream);
+    hipStream_t  stream = nullptr;
+    double      *coef[2] = {nullptr, nullptr};
+    e = hipStreamCreate(&stream);
+    if (e != hipSuccess)
+      return hip_fail(h, e, "hipStreamCreate");
+    const size_t bytes = (size_t)h->cfg.n_problems * h->NE * h->NE * 4 * sizeof(double);
+    for (int f = 0; f < h->cfg.spacedim && e == hipSuccess; ++f)
+      e = hipMalloc((void **)&coef[f], bytes);
     if (e != hipSuccess)
       {
-        h->stream = nullptr;
-        return hip_fail(h, e, "hipStreamCreate");
+        // nothing half-initialised is kept: the next call starts from scratch
+        for (int f = 0; f < 2; ++f)
+          if (coef[f])
+            (void)hipFree(coef[f]);
+        (void)hipStreamDestroy(stream);
+        return hip_fail(h, e, "hipMalloc(coefficient field)");
       }
-    const size_t bytes = (size_t)h->cfg.n_problems * h->NE * h->NE * 4 * sizeof(double);
-    for (int f = 0; f < h->cfg.spacedim; ++f)
-      {
-        e = hipMalloc((void **)&h->d_coef[f], bytes);
-        if (e != hipSuccess)
-          return hip_fail(h, e, "hipMalloc(coefficient field)");
-      }
+    h->stream       = stream;
+    h->d_coef[0]    = coef[0];
+    h->d_coef[1]    = coef[1];
+    h->device_ready = true;
     return SLOD_OK;
   }
 
@@ -227,8 +241,10 @@ namespace
     a.NE          = h->NE;
     a.n_sub       = h->cfg.n_subdivisions;
     a.quirk       = h->cfg.projection_quirk;
-    if (const char *dg = std::getenv("SLOD_DIAG"))
-      a.diag = std::atoi(dg); // timing experiments only: results are wrong when non-zero
+#ifdef SLOD_ENABLE_DIAG
+    if (const char *dg = std::getenv("SLOD_DIAG")) // lib/libslod_hip_diag.so only (tools/)
+      a.diag = std::atoi(dg); // timing experiments: results are wrong when non-zero
+#endif
     const double H = 1.0 / (double)h->N, hh = H / (double)h->cfg.n_subdivisions;
     a.scale     = hh * hh / 4.0; // LOD.cc:341
     a.invH2     = 1.0 / (H * H); // LOD.cc:551
@@ -250,10 +266,12 @@ namespace
     a.basis     = d_basis;
     a.premult   = d_premult;
     a.status    = p->d_status;
+    a.pdiag     = p->d_pdiag ? p->d_pdiag + first * (size_t)h->cfg.spacedim : nullptr;
     return a;
   }
 } // namespace
 
+#pragma GCC visibility push(default)
 extern "C" {
 
 int slod_abi_version(void) { return SLOD_ABI_VERSION; }
@@ -514,22 +532,16 @@ int slod_plan_create(slod_handle *h, const uint32_t *gids, size_t n, const uint6
   // k_select reduces the boundary-trace matrix by QR in row chunks (TSQR): the LDS buffer
   // holds nb_buf rows, at least nc_max + 16 so every chunk brings new rows
   p->nb_buf = std::min(p->nb_max, std::max(96, p->nc_max + 16));
-  const size_t lds_max = 160 * 1024;
-  if ((slod_solve_lds_bytes(s, p->m_max, p->nc_max, 0) > lds_max &&
-       !(slod_solve_ws_tile(p->m_max) && (slod_solve_ws_lds_bytes(s, p->m_max, p->nc_max) <= lds_max ||
-                                          slod_solve_tw_lds_bytes(s, p->m_max, p->nc_max) <= lds_max))) ||
-      slod_select_lds_bytes(s, p->nb_buf, p->nc_max, p->nf_max) > lds_max)
+  // the kernel family, its LDS size and the fused stages are fixed here, once (the same function
+  // the launch uses): a plan that no kernel can run is rejected now, not at execute
+  if (!slod_choose_solver(s, p->m_max, p->nc_max, p->nb_buf, p->nf_max, n, slod_read_tuning(), &p->choice))
     {
       delete p;
-      return fail(h, SLOD_ERR_UNSUPPORTED, "slod_plan_create: patch does not fit the 160 KB LDS");
+      return fail(h, SLOD_ERR_UNSUPPORTED, "slod_plan_create: patch does not fit the 160 KB LDS of any solver kernel");
     }
   p->nn_max    = (p->nn_max + 31) & ~31; // 256-byte aligned stencil planes
   p->st_stride = (size_t)9 * s * s * p->nn_max;
-  {
-    // k_solve_ws stores V lines as (8T)^2 blocks; the cooperative kernel as m_max^2
-    const int mp = std::max(p->m_max, 8 * slod_solve_ws_tile(p->m_max));
-    p->v_stride  = (size_t)p->L_max * mp * mp;
-  }
+  p->v_stride  = (size_t)p->L_max * p->choice.v_line_pad * p->choice.v_line_pad;
   p->x_stride  = (size_t)p->L_max * p->m_max * p->nc_max;
   const size_t per_patch = (p->st_stride + p->v_stride + p->x_stride) * sizeof(double);
   size_t       budget_mb = 24 * 1024;
@@ -543,6 +555,8 @@ int slod_plan_create(slod_handle *h, const uint32_t *gids, size_t n, const uint6
   ok       = ok && hipMalloc((void **)&p->ws_x, p->chunk * p->x_stride * sizeof(double)) == hipSuccess;
   ok       = ok && hipMalloc((void **)&p->ws_m, p->chunk * (size_t)p->nc_max * p->nc_max * sizeof(double)) == hipSuccess;
   ok       = ok && hipMalloc((void **)&p->d_status, sizeof(int32_t)) == hipSuccess;
+  ok       = ok && hipMalloc((void **)&p->d_pdiag, n * (size_t)s * sizeof(SlodPatchDiag)) == hipSuccess;
+  ok       = ok && hipMemset(p->d_pdiag, 0, n * (size_t)s * sizeof(SlodPatchDiag)) == hipSuccess;
   ok = ok && hipMemcpy(p->d_desc, p->desc.data(), n * sizeof(SlodPatchDesc), hipMemcpyHostToDevice) ==
                hipSuccess;
   ok = ok && hipMemset(p->d_status, 0, sizeof(int32_t)) == hipSuccess;
@@ -579,6 +593,8 @@ void slod_plan_destroy(slod_plan *p)
     (void)hipFree(p->ws_m);
   if (p->d_status)
     (void)hipFree(p->d_status);
+  if (p->d_pdiag)
+    (void)hipFree(p->d_pdiag);
   delete p;
 }
 
@@ -609,13 +625,12 @@ int slod_plan_execute(slod_plan *p, double *d_basis, double *d_premult, void *hi
       SlodKernelArgs       a   = make_args(p, first, d_basis, d_premult);
       hipEvent_t          *ev  = &p->ev[4 * ((p->n_exec % (size_t)p->depth) * p->n_chunks + ci)];
       e = hipEventRecord(ev[0], st);
-      a.fuse_assemble = slod_solve_fuses_assemble(s, a) ? 1 : 0;
-      if (e == hipSuccess && !a.fuse_assemble)
+      if (e == hipSuccess && !p->choice.fuse_assemble)
         e = slod_launch_assemble(s, a, cnt, st);
       if (e == hipSuccess)
         e = hipEventRecord(ev[1], st);
       if (e == hipSuccess)
-        e = slod_launch_solve(s, a, cnt, st); // sets a.m_fused, a.fuse_select
+        e = slod_launch_solve(s, p->choice, a, cnt, st); // sets a.m_fused, a.fuse_select, a.fuse_assemble
       if (e == hipSuccess)
         e = hipEventRecord(ev[2], st);
       if (e == hipSuccess && !a.fuse_select)
@@ -630,8 +645,29 @@ int slod_plan_execute(slod_plan *p, double *d_basis, double *d_premult, void *hi
   return SLOD_OK;
 }
 
-// timing experiments only (not part of include/slod.h): the per-patch scratch block `ms` of the
-// first workspace chunk, which the kernels fill with clock stamps under SLOD_DIAG bit 20
+int slod_plan_diagnostics(slod_plan *p, slod_patch_diag *out, size_t capacity)
+{
+  static_assert(sizeof(slod_patch_diag) == sizeof(SlodPatchDiag), "slod_patch_diag layout");
+  if (!p || (!out && p->n))
+    return SLOD_ERR_ARGUMENT;
+  const size_t cnt = p->n * (size_t)p->h->cfg.spacedim;
+  if (capacity < cnt)
+    return fail(p->h, SLOD_ERR_ARGUMENT, "slod_plan_diagnostics: buffer too small");
+  if (!p->ran)
+    return fail(p->h, SLOD_ERR_STATE, "slod_plan_diagnostics: plan has not been executed");
+  (void)hipSetDevice(p->h->cfg.device);
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess)
+    e = hipMemcpy(out, p->d_pdiag, cnt * sizeof(SlodPatchDiag), hipMemcpyDeviceToHost);
+  if (e != hipSuccess)
+    return hip_fail(p->h, e, "slod_plan_diagnostics");
+  return (int)cnt;
+}
+
+#ifdef SLOD_ENABLE_DIAG
+// timing experiments only (lib/libslod_hip_diag.so, not part of include/slod.h): the per-patch
+// scratch block `ms` of the first workspace chunk, which the kernels fill with clock stamps under
+// SLOD_DIAG bit 20
 int slod_debug_read_ms(slod_plan *p, double *out, size_t count)
 {
   if (!p || !out)
@@ -643,6 +679,7 @@ int slod_debug_read_ms(slod_plan *p, double *out, size_t count)
              ? SLOD_OK
              : SLOD_ERR_DEVICE;
 }
+#endif
 
 int slod_plan_profile(slod_plan *p, int depth)
 {
@@ -860,3 +897,4 @@ int slod_patch_solution(slod_handle *h, uint32_t gid, double *X)
 }
 
 } // extern "C"
+#pragma GCC visibility pop

@@ -29,6 +29,26 @@ enum : int32_t
   SLOD_F_TRANSPOSED = 1 << 5
 };
 
+// Phase-skip / timeline masks of the timing experiments (tools/): compiled in only with
+// -DSLOD_ENABLE_DIAG (lib/libslod_hip_diag.so); the release library has no such branches.
+#ifdef SLOD_ENABLE_DIAG
+#define SLOD_DG(A, mask) ((A).diag & (mask))
+#else
+#define SLOD_DG(A, mask) 0
+#endif
+
+// Decisions of the SLOD selection stage for one (patch, component): what include/slod.h
+// exposes as slod_patch_diag (same layout).
+struct SlodPatchDiag
+{
+  int32_t path;      // 0 LOD branch, 1 SLOD without decisions (QR, proven), 2 SLOD with SVD replay
+  int32_t n_cut;     // singular values of G under the 1e-15 cutoff (LOD.cc:667)
+  int32_t n_dropped; // triplets removed by the 0.5-loop (LOD.cc:703-725)
+  int32_t sweeps;    // Jacobi sweeps of the SVD replay
+  double  dinf;      // final ||d||_inf
+  double  sigma_max, sigma_min; // extreme singular values of G (path 2), else 0
+};
+
 struct SlodKernelArgs
 {
   const SlodPatchDesc *desc; // [n_patches of this launch]
@@ -38,7 +58,8 @@ struct SlodKernelArgs
   int32_t              NE;          // fine elements per side of the global grid
   int32_t              n_sub;
   int32_t              quirk;       // projection quirk Q2
-  int32_t              diag;        // timing diagnostics only (env SLOD_DIAG): phase skip mask
+  int32_t              diag;        // timing experiments (SLOD_ENABLE_DIAG builds only): phase skip mask
+  int32_t              debug;       // print the launch configuration (SLOD_DEBUG)
   double               scale;       // h^2/4
   double               invH2;       // 1/H^dim
   // workspace (one slot per patch of the launch)
@@ -61,12 +82,40 @@ struct SlodKernelArgs
   double  *basis;
   double  *premult;
   int32_t *status;
+  SlodPatchDiag *pdiag; // [patches of the launch][S]
 };
 
-// launchers (slod_assemble.hip, slod_solve_{tw,ws,coop}.hip, slod_select.hip)
+enum SlodSolverKind : int32_t
+{
+  SLOD_K_MF   = 1, // slod_solve_mf.hip
+  SLOD_K_TW   = 2, // slod_solve_tw.hip
+  SLOD_K_WS   = 3, // slod_solve_ws.hip
+  SLOD_K_COOP = 4  // slod_solve_coop.hip
+};
+
+// tuning knobs (environment, read once per plan) and the resulting kernel choice: slod_dispatch.cpp
+struct SlodTuning
+{
+  int solver = 0;        // 0 = automatic, else a SlodSolverKind
+  int fuse_select = 1, fuse_assemble = 1, fuse_m = 0;
+  int twisted = -1;      // coop kernel only: -1 = automatic
+  int debug = 0;
+};
+struct SlodSolveChoice
+{
+  int    kind = 0;
+  size_t lds  = 0;
+  int    fuse_select = 0, fuse_assemble = 0, m_fused = 0, twisted = 0, debug = 0;
+  int    v_line_pad = 0; // rows = columns of a stored V line in the workspace
+};
+SlodTuning slod_read_tuning();
+bool       slod_choose_solver(int S, int m_max, int nc_max, int nb_buf, int nf_max, size_t n_patches,
+                              const SlodTuning &t, SlodSolveChoice *out);
+
+// launchers (slod_assemble.hip, slod_solve_{mf,tw,ws,coop}.hip, slod_select.hip)
 hipError_t slod_launch_assemble(int S, const SlodKernelArgs &a, int n_patches, hipStream_t st);
-hipError_t slod_launch_solve(int S, SlodKernelArgs &a, int n_patches, hipStream_t st); // slod_dispatch.cpp
-bool       slod_solve_fuses_assemble(int S, const SlodKernelArgs &a);               // slod_dispatch.cpp
+hipError_t slod_launch_solve(int S, const SlodSolveChoice &c, SlodKernelArgs &a, int n_patches, hipStream_t st);
+hipError_t slod_launch_solve_mf(int S, const SlodKernelArgs &a, int n_patches, size_t lds, hipStream_t st);
 hipError_t slod_launch_solve_tw(int S, const SlodKernelArgs &a, int n_patches, size_t lds, hipStream_t st);
 hipError_t slod_launch_solve_ws(int S, const SlodKernelArgs &a, int n_patches, size_t lds, hipStream_t st);
 hipError_t slod_launch_solve_coop(int S, int twisted, const SlodKernelArgs &a, int n_patches, hipStream_t st);
@@ -75,7 +124,9 @@ hipError_t slod_launch_select(int S, const SlodKernelArgs &a, int n_patches, int
 size_t     slod_solve_lds_bytes(int S, int m_max, int nc_max, int twisted);
 size_t     slod_solve_ws_lds_bytes(int S, int m_max, int nc_max);
 size_t     slod_solve_tw_lds_bytes(int S, int m_max, int nc_max);
+size_t     slod_solve_mf_lds_bytes(int S, int m_max, int nc_max);
 int        slod_solve_ws_tile(int m_max);
+int        slod_solve_mf_tiles(int S, int m_max); // 16 x 16 tiles per line side, 0 = does not fit
 size_t     slod_select_lds_bytes(int S, int nb_max, int nc_max, int nf_max);
 
 #endif

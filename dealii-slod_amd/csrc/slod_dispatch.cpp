@@ -1,60 +1,123 @@
-// Solver kernel choice (host code).
+// Solver kernel choice (host code): ONE function decides which patch-solve kernel a plan uses,
+// with which LDS size and which stages fused in.  slod_plan_create calls it (and rejects the plan
+// when nothing fits), slod_plan_execute launches exactly that choice.
 #include "slod_device.h"
 
 #include <cstdlib>
 #include <cstring>
 
-// true when slod_launch_solve will pick k_solve_tw for a scalar problem: that kernel then assembles
-// the stencil itself (SLOD_FUSE_ASSEMBLE=0 keeps the separate k_assemble launch)
-bool slod_solve_fuses_assemble(int S, const SlodKernelArgs &a)
+// Tuning knobs of the experiments in tools/ and of the kernel-variant parity tests; read once
+// per plan (slod_plan_create), never in the launch path.
+//   SLOD_SOLVE=mf|tw|ws|coop  force a kernel family       SLOD_FUSE_SELECT=0  selection as its own launch
+//   SLOD_FUSE_ASSEMBLE=0      stencil assembly as its own launch
+//   SLOD_FUSE_M=1 (ws only)   SLOD_TWISTED=0|1 (coop only) SLOD_DEBUG=1 print the choice
+SlodTuning slod_read_tuning()
 {
-  const char *sel = getenv("SLOD_SOLVE");
-  const char *fa  = getenv("SLOD_FUSE_ASSEMBLE");
-  const bool  fits = slod_solve_ws_tile(a.m_max) >= 2 * S - 1 && slod_solve_ws_tile(a.m_max) > 0;
-  return S == 1 && !(fa && !atoi(fa)) && fits && (!sel || !strcmp(sel, "tw")) &&
-         slod_solve_tw_lds_bytes(S, a.m_max, a.nc_max) <= 160 * 1024;
+  SlodTuning t;
+  if (const char *sel = getenv("SLOD_SOLVE"))
+    t.solver = !strcmp(sel, "mf") ? SLOD_K_MF : !strcmp(sel, "tw") ? SLOD_K_TW : !strcmp(sel, "ws") ? SLOD_K_WS :
+               !strcmp(sel, "coop") ? SLOD_K_COOP : 0;
+  if (const char *e = getenv("SLOD_FUSE_SELECT"))
+    t.fuse_select = atoi(e) ? 1 : 0;
+  if (const char *e = getenv("SLOD_FUSE_ASSEMBLE"))
+    t.fuse_assemble = atoi(e) ? 1 : 0;
+  if (const char *e = getenv("SLOD_FUSE_M"))
+    t.fuse_m = atoi(e) ? 1 : 0;
+  if (const char *e = getenv("SLOD_TWISTED"))
+    t.twisted = atoi(e) ? 1 : 0;
+  if (const char *e = getenv("SLOD_DEBUG"))
+    t.debug = atoi(e) ? 1 : 0;
+  return t;
 }
 
-hipError_t slod_launch_solve(int S, SlodKernelArgs &a, int n_patches, hipStream_t st)
+bool slod_choose_solver(int S, int m_max, int nc_max, int nb_buf, int nf_max, size_t n_patches, const SlodTuning &t,
+                        SlodSolveChoice *out)
 {
-  a.m_fused = 0;
-  a.fuse_select = 0;
-  // Kernel choice (SLOD_SOLVE=tw|ws|coop forces one):
-  //   tw   twisted + wave-specialised (default): two GJ waves + two helper waves per patch
-  //   ws   wave-specialised, one chain: one GJ wave + three helpers (keeps V, Z in LDS)
-  //   coop all threads cooperate on every pivot (k_solve, also for tiles narrower than the band)
-  {
-    const char *sel  = getenv("SLOD_SOLVE");
-    const bool  fits = slod_solve_ws_tile(a.m_max) >= 2 * S - 1 && slod_solve_ws_tile(a.m_max) > 0;
-    const bool  want_tw = !sel || !strcmp(sel, "tw"), want_ws = !sel || !strcmp(sel, "ws") || !strcmp(sel, "tw");
-    if (fits && want_tw && slod_solve_tw_lds_bytes(S, a.m_max, a.nc_max) <= 160 * 1024)
-      {
-        size_t lds = slod_solve_tw_lds_bytes(S, a.m_max, a.nc_max);
-        // the selection stage runs in the same launch (scalar problems; SLOD_FUSE_SELECT=0 splits it off)
-        const char  *fs   = getenv("SLOD_FUSE_SELECT");
-        const size_t lds2 = slod_select_lds_bytes(S, a.nb_buf, a.nc_max, a.nf_max);
-        a.fuse_select     = (S == 1 && !(fs && !atoi(fs)) && lds2 <= 64 * 1024) ? 1 : 0;
-        if (a.fuse_select && lds2 > lds)
-          lds = lds2;
-        return slod_launch_solve_tw(S, a, n_patches, lds, st);
-      }
-    if (fits && want_ws && slod_solve_ws_lds_bytes(S, a.m_max, a.nc_max) <= 160 * 1024)
-      {
-        const size_t lds = slod_solve_ws_lds_bytes(S, a.m_max, a.nc_max);
-        // fusing M = sum_l R_l^T Z_l into the helper waves saves k_select's re-read of X but
-        // costs a fourth barrier per line; measured neutral on C2, so opt-in (SLOD_FUSE_M=1)
-        const char *fm = getenv("SLOD_FUSE_M");
-        a.m_fused      = (fm && atoi(fm) && a.nc_max * a.nc_max <= 192 * 4) ? 1 : 0;
-        return slod_launch_solve_ws(S, a, n_patches, lds, st);
-      }
-  }
-  // twisted (two chains, 512 threads) when the GPU is not full anyway: it halves the
-  // dependent chain per patch; one chain per patch otherwise (same work, more patches
-  // resident).  SLOD_TWISTED=0/1 overrides.
-  int tw = n_patches < 3 * 256 ? 1 : 0;
-  if (const char *env = getenv("SLOD_TWISTED"))
-    tw = atoi(env) ? 1 : 0;
-  if (slod_solve_lds_bytes(S, a.m_max, a.nc_max, tw) > 160 * 1024)
-    tw = 0;
-  return slod_launch_solve_coop(S, tw, a, n_patches, st);
+  const size_t    lds_max = 160 * 1024;
+  SlodSolveChoice c;
+  c.debug = t.debug;
+  // Kernel families:
+  //   mf   MFMA-factorised: blocked Gauss-Jordan on the fp64 matrix pipe, twisted, column-tile
+  //        private right-hand-side streams (default wherever it fits)
+  //   tw   twisted + wave-specialised VALU Gauss-Jordan
+  //   ws   wave-specialised, one chain
+  //   coop all threads cooperate on every pivot (also for tiles narrower than the band)
+  const int  wt = slod_solve_ws_tile(m_max);
+  const bool ws_fits = wt > 0 && wt >= 2 * S - 1;
+  const auto want = [&](int k) { return t.solver == 0 || t.solver == k; };
+  const size_t lds_sel = slod_select_lds_bytes(S, nb_buf, nc_max, nf_max);
+  if (want(SLOD_K_MF) && slod_solve_mf_tiles(S, m_max) > 0 && slod_solve_mf_lds_bytes(S, m_max, nc_max) <= lds_max)
+    {
+      c.kind          = SLOD_K_MF;
+      c.lds           = slod_solve_mf_lds_bytes(S, m_max, nc_max);
+      c.v_line_pad    = 16 * slod_solve_mf_tiles(S, m_max);
+      c.fuse_assemble = (S == 1 && t.fuse_assemble) ? 1 : 0;
+      c.fuse_select   = (S == 1 && t.fuse_select && lds_sel <= lds_max) ? 1 : 0;
+      if (c.fuse_select && lds_sel > c.lds)
+        c.lds = lds_sel;
+    }
+  else if (want(SLOD_K_TW) && (t.solver == SLOD_K_TW || wt <= 6) && ws_fits &&
+           slod_solve_tw_lds_bytes(S, m_max, nc_max) <= lds_max)
+    {
+      c.kind          = SLOD_K_TW;
+      c.lds           = slod_solve_tw_lds_bytes(S, m_max, nc_max);
+      c.v_line_pad    = 8 * wt;
+      c.fuse_assemble = (S == 1 && t.fuse_assemble) ? 1 : 0;
+      // the selection stage runs in the same launch (scalar problems) while four workgroups
+      // still fit a CU
+      c.fuse_select = (S == 1 && t.fuse_select && lds_sel <= 64 * 1024) ? 1 : 0;
+      if (c.fuse_select && lds_sel > c.lds)
+        c.lds = lds_sel;
+    }
+  else if ((want(SLOD_K_WS) || t.solver == SLOD_K_TW) && (t.solver != 0 || wt <= 6) && ws_fits &&
+           slod_solve_ws_lds_bytes(S, m_max, nc_max) <= lds_max)
+    {
+      c.kind       = SLOD_K_WS;
+      c.lds        = slod_solve_ws_lds_bytes(S, m_max, nc_max);
+      c.v_line_pad = 8 * wt;
+      // fusing M = sum_l R_l^T Z_l into the helper waves saves the selection stage's re-read of X
+      // but costs a fourth barrier per line; measured neutral on C2, so opt-in (SLOD_FUSE_M=1)
+      c.m_fused = (t.fuse_m && nc_max * nc_max <= 192 * 4) ? 1 : 0;
+    }
+  else if (t.solver == 0 || t.solver == SLOD_K_COOP || !ws_fits)
+    {
+      // twisted (two chains, 512 threads) when the GPU is not full anyway: it halves the
+      // dependent chain per patch; one chain per patch otherwise
+      int tw = t.twisted >= 0 ? t.twisted : (n_patches < 3 * 256 ? 1 : 0);
+      if (slod_solve_lds_bytes(S, m_max, nc_max, tw) > lds_max)
+        tw = 0;
+      if (slod_solve_lds_bytes(S, m_max, nc_max, tw) > lds_max || (m_max + 15) / 16 > 7)
+        return false;
+      c.kind       = SLOD_K_COOP;
+      c.twisted    = tw;
+      c.lds        = slod_solve_lds_bytes(S, m_max, nc_max, tw);
+      c.v_line_pad = m_max;
+    }
+  else
+    return false;
+  if (!c.fuse_select && lds_sel > lds_max)
+    return false; // the stand-alone selection launch does not fit either
+  *out = c;
+  return true;
+}
+
+hipError_t slod_launch_solve(int S, const SlodSolveChoice &c, SlodKernelArgs &a, int n_patches, hipStream_t st)
+{
+  a.m_fused       = c.m_fused;
+  a.fuse_select   = c.fuse_select;
+  a.fuse_assemble = c.fuse_assemble;
+  a.debug         = c.debug;
+  switch (c.kind)
+    {
+      case SLOD_K_MF:
+        return slod_launch_solve_mf(S, a, n_patches, c.lds, st);
+      case SLOD_K_TW:
+        return slod_launch_solve_tw(S, a, n_patches, c.lds, st);
+      case SLOD_K_WS:
+        return slod_launch_solve_ws(S, a, n_patches, c.lds, st);
+      case SLOD_K_COOP:
+        return slod_launch_solve_coop(S, c.twisted, a, n_patches, st);
+      default:
+        return hipErrorInvalidValue;
+    }
 }

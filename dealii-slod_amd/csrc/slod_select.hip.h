@@ -92,7 +92,7 @@ namespace
     __syncthreads();
 
     // timing experiments (SLOD_DIAG bit 20): thread 0 stamps the 100 MHz clock per phase into ms
-    const bool stamping = (A.diag & (1 << 20)) && tid == 0;
+    const bool stamping = (SLOD_DG(A, (1 << 20))) && tid == 0 && A.nc_max * A.nc_max >= 12;
     double    *msd      = A.ms + (size_t)patch * A.nc_max * A.nc_max;
     double     tph[3]   = {0.0, 0.0, 0.0};
     double     tlast    = stamping ? (double)wall_clock64() : 0.0;
@@ -120,7 +120,7 @@ namespace
       }
     // M = P^T A^-1 P is symmetric and the sweep below treats it as such (column k is taken from
     // row k), so only the entries a <= b are computed (half the load batches) and mirrored
-    for (int idx = tid; idx < ((A.diag & 64) || A.m_fused ? 0 : nc * (nc + 1) / 2); idx += 256)
+    for (int idx = tid; idx < ((SLOD_DG(A, 64)) || A.m_fused ? 0 : nc * (nc + 1) / 2); idx += 256)
       {
         // row a of the upper triangle holds nc - a entries: a = largest a with a (2 nc - a + 1) / 2 <= idx
         int a = (int)((2.0f * nc + 1.0f - sqrtf((2.0f * nc + 1.0f) * (2.0f * nc + 1.0f) - 8.0f * idx)) * 0.5f);
@@ -213,12 +213,12 @@ namespace
               cvec[mj[e]] = mv[e];
           }
         __syncthreads();
-        for (int k = 0; k < ((A.diag & 128) ? 0 : nc); ++k)
+        for (int k = 0; k < ((SLOD_DG(A, 128)) ? 0 : nc); ++k)
           {
             const double *rk  = (k & 1) ? rowk : cvec;
             double       *rn  = (k & 1) ? cvec : rowk;
             const double  piv = rk[k];
-            if (tid == 0 && !(piv > 0.0) && !A.diag)
+            if (tid == 0 && !(piv > 0.0) && !SLOD_DG(A, -1))
               atomicOr(A.status, 2);
             const double p = fast_rcp(piv);
 #pragma unroll
@@ -248,13 +248,13 @@ namespace
       }
     else
       {
-        for (int k = 0; k < ((A.diag & 128) ? 0 : nc); ++k)
+        for (int k = 0; k < ((SLOD_DG(A, 128)) ? 0 : nc); ++k)
           {
             for (int j = tid; j < nc; j += 256)
               rowk[j] = Ms[k * ldm + j];
             __syncthreads();
             const double piv = rowk[k];
-            if (tid == 0 && !(piv > 0.0) && !A.diag)
+            if (tid == 0 && !(piv > 0.0) && !SLOD_DG(A, -1))
               atomicOr(A.status, 2);
             const double p = fast_rcp(piv);
             for (int idx = tid; idx < nc * nc; idx += 256)
@@ -286,8 +286,11 @@ namespace
       {
         for (int j = tid; j < nc; j += 256)
           gam[j] = (j == dsel) ? 1.0 : 0.0;
+        // decisions of this (patch, component), reported through slod_plan_diagnostics (thread 0)
+        SlodPatchDiag pdg = {0, 0, 0, 0, 0.0, 0.0, 0.0};
         if (!lod)
           {
+            pdg.path = 1;
             // ---- BD = (S_BI X_I - P^T_B) D (LOD.cc:609-618), built in row chunks that fit the
             //      LDS buffer (nbuf rows) and reduced by Householder QR chunk after chunk
             //      (TSQR): after every chunk the top nn1 rows hold the R factor of all rows
@@ -387,7 +390,7 @@ namespace
             };
             // one pass over all boundary rows when they fit the registers (<= 160 rows): the row chunks
             // only stage BD through LDS (fill, * D), a single sweep of nn1 reflectors follows
-            const bool onepass = nb <= 160 && nb > 96 && nc <= 32 && (nbuf & 15) == 0 && !(A.diag & (512 | 262144));
+            const bool onepass = nb <= 160 && nb > 96 && nc <= 32 && (nbuf & 15) == 0 && !(SLOD_DG(A, (512 | 262144)));
             double     aq[2][10];
             for (int r0 = 0; r0 < nb;)
               {
@@ -399,7 +402,7 @@ namespace
                 // works on U entries at once.  Lanes run along the columns of a row (coalesced X rows).
                 {
                   constexpr int U = 2;
-                  for (int idx0 = tid; idx0 < ((A.diag & 256) ? 0 : take * nc); idx0 += 256 * U)
+                  for (int idx0 = tid; idx0 < ((SLOD_DG(A, 256)) ? 0 : take * nc); idx0 += 256 * U)
                     {
                       double sv[U][3][S], xv[U][3][S], acc[U];
                       int    dst[U];
@@ -510,7 +513,7 @@ namespace
                 r0 += take;
                 const int rows = filled + take;
                 nr             = rows;
-                if (rows < nn1 || (A.diag & 512))
+                if (rows < nn1 || (SLOD_DG(A, 512)))
                   {
                     filled = rows; // fewer rows than columns so far
                     if (filled >= nbuf)
@@ -668,7 +671,7 @@ namespace
                 tacc(2);
                 nr = nn1;
               }
-            if (did_qr && !(A.diag & 512))
+            if (did_qr && !(SLOD_DG(A, 512)))
               {
                 if (!singular)
                   {
@@ -718,6 +721,7 @@ namespace
                       red[4 + wave] = dmax;
                     __syncthreads();
                     const double dinf = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+                    pdg.dinf          = dinf;
                     if (nr2 * ni2 < 1e14 && dinf < 0.5 - 1e-9)
                       {
                         need_svd = false;
@@ -733,8 +737,9 @@ namespace
                 msd[7] = tph[2];
               }
             stamp(8);
-            if (need_svd && !(A.diag & (512 | 4096)))
+            if (need_svd && !(SLOD_DG(A, (512 | 4096))))
               {
+                pdg.path = 2;
                 // ---- one-sided Jacobi SVD (the reference's singular triplets are needed).
                 // After the QR the sweeps run on L = R^T (Drmac/Veselic: much faster convergence
                 // than on R): L J = W with orthogonal columns w_j = sigma_j v_j (v_j = right
@@ -748,7 +753,7 @@ namespace
                 int        pb     = 0;               // current buffer of the column order pcol
                 for (int j = tid; j < nn1; j += 256)
                   pcol[j] = j;
-                if (tposed && nc <= 32 && !(A.diag & 65536))
+                if (tposed && nc <= 32 && !(SLOD_DG(A, 65536)))
                   {
                     // Second-stage QR of R WITH column pivoting, R P = Q' R' (Drmac/Veselic
                     // preconditioning: the sweeps on R'^T converge in ~6 instead of ~10 sweeps).
@@ -894,7 +899,7 @@ namespace
                     fro            = fma(w, w, fro);
                   }
                 const double tiny = 1e-22 * block_sum(fro);
-                if (nev / 2 <= 16 && (A.diag & 131072))
+                if (nev / 2 <= 16 && (SLOD_DG(A, 131072)))
                   {
                     // All nev/2 <= 16 column pairs of a round fit ONE wave (4 lanes per pair): wave 0
                     // runs the sweeps alone, LDS accesses of one wave execute in order, so a round
@@ -903,7 +908,7 @@ namespace
                     if (wave == 0)
                       {
                         const int l4 = lane & 3, pr = lane >> 2;
-                        for (int sweep = 0; sweep < ((A.diag & 8192) ? 3 : 40); ++sweep)
+                        for (int sweep = 0; sweep < ((SLOD_DG(A, 8192)) ? 3 : 40); ++sweep)
                           {
                             bool any = false;
                             for (int round = 0; round < nev - 1; ++round)
@@ -969,7 +974,7 @@ namespace
                     __syncthreads();
                   }
                 else
-                  for (int sweep = 0; sweep < ((A.diag & 8192) ? 3 : 40); ++sweep)
+                  for (int sweep = 0; sweep < ((SLOD_DG(A, 8192)) ? 3 : 40); ++sweep)
                     {
                       if (tid == 0)
                         flag[0] = 0;
@@ -1034,6 +1039,7 @@ namespace
                         }
                       const int any = flag[0];
                       __syncthreads();
+                      ++pdg.sweeps;
                       if (!any)
                         break;
                     }
@@ -1073,6 +1079,10 @@ namespace
                 __syncthreads();
                 {
                   const double s0 = sig[ord[0]];
+                  pdg.sigma_max   = s0;
+                  pdg.sigma_min   = sig[ord[nn1 - 1]];
+                  if (wave == 0) // nn1 <= 63: one ballot counts the cut singular values
+                    pdg.n_cut = __popcll(__ballot(tid < nn1 && !(sig[min(tid, nn1 - 1)] > 1e-15 * s0)));
                   for (int j = tid; j < nn1; j += 256)
                     utg[j] = (sig[j] > 1e-15 * s0) ? utg[j] / sig[j] : 0.0;
                 }
@@ -1088,17 +1098,28 @@ namespace
                   {
                     // all components live in wave 0: no workgroup barrier per removal
                     if (wave == 0)
-                      for (int r = nn1 - 1; r >= 0; --r)
-                        {
-                          double dmax = (tid < nn1) ? fabs(del) : 0.0;
-                          for (int off = 32; off > 0; off >>= 1)
-                            dmax = fmax(dmax, __shfl_xor(dmax, off, 64));
-                          if (dmax < 0.5)
-                            break;
-                          const int j = ord[r];
-                          if (tid < nn1)
-                            del = fma(tvec(tid, j), utg[j], del);
-                        }
+                      {
+                        for (int r = nn1 - 1; r >= 0; --r)
+                          {
+                            double dmax = (tid < nn1) ? fabs(del) : 0.0;
+                            for (int off = 32; off > 0; off >>= 1)
+                              dmax = fmax(dmax, __shfl_xor(dmax, off, 64));
+                            pdg.dinf = dmax;
+                            if (dmax < 0.5)
+                              break;
+                            const int j = ord[r];
+                            if (tid < nn1)
+                              del = fma(tvec(tid, j), utg[j], del);
+                            ++pdg.n_dropped;
+                          }
+                        if (pdg.n_dropped == nn1) // every triplet removed: d = 0 (up to rounding)
+                          {
+                            double dmax = (tid < nn1) ? fabs(del) : 0.0;
+                            for (int off = 32; off > 0; off >>= 1)
+                              dmax = fmax(dmax, __shfl_xor(dmax, off, 64));
+                            pdg.dinf = dmax;
+                          }
+                      }
                   }
                 else
                   for (int r = nn1 - 1; r >= 0; --r)
@@ -1111,16 +1132,20 @@ namespace
                         red[4 + wave] = dmax;
                       __syncthreads();
                       const double dinf = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+                      pdg.dinf = dinf;
                       if (dinf < 0.5)
                         break;
                       const int j = ord[r];
                       if (tid < nn1)
                         del = fma(tvec(tid, j), utg[j], del);
+                      ++pdg.n_dropped;
                     }
                 if (tid < nn1)
                   gam[cix(pc[tid])] = del; // component of the pc[tid]-th column of BD'
               }
           }
+        if (tid == 0 && A.pdiag)
+          A.pdiag[(size_t)patch * S + dsel] = pdg;
         __syncthreads();
         stamp(9);
         // ---- c = D gamma (LOD.cc:727-743 / 576-577)
@@ -1134,7 +1159,7 @@ namespace
         __syncthreads();
         // ---- phi = X c, zero on the boundary (LOD.cc:745-750), l2-normalised (LOD.cc:752)
         double ssq = 0.0;
-        for (int dof = tid; dof < ((A.diag & 1024) ? 0 : nf); dof += 256)
+        for (int dof = tid; dof < ((SLOD_DG(A, 1024)) ? 0 : nf); dof += 256)
           {
             const int     node = dof / S, comp = dof - node * S;
             const int     ix = node % npx, iy = node / npx;
@@ -1166,7 +1191,7 @@ namespace
         __syncthreads();
         stamp(10);
         // ---- psi = A_semi phi: identity rows on id-0 dofs (LOD.cc:537-541,758-765)
-        for (int dof = tid; dof < ((A.diag & 2048) ? 0 : nf); dof += 256)
+        for (int dof = tid; dof < ((SLOD_DG(A, 2048)) ? 0 : nf); dof += 256)
           {
             const int  node = dof / S, comp = dof - node * S;
             const int  ix = node % npx, iy = node / npx;

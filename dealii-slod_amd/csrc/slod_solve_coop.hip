@@ -117,7 +117,7 @@ namespace
           for (int e = 0; e < BW; ++e)
             {
               const int p = i + e - W;
-              bi[e] = (have_prev && i < m && p >= 0 && p < m && !(A.diag & 1)) ? Bp[p * BW + (2 * W - e)] : 0.0;
+              bi[e] = (have_prev && i < m && p >= 0 && p < m && !(SLOD_DG(A, 1))) ? Bp[p * BW + (2 * W - e)] : 0.0;
             }
 #pragma unroll
           for (int rb = 0; rb < R; ++rb)
@@ -144,7 +144,7 @@ namespace
     };
     // Rb = F_line - Bp^T Zp ; F = rows of P^T (LOD.cc:478-495)
     auto build_R = [&](int line, bool have_prev, bool with_F) __attribute__((always_inline)) {
-      if (A.diag & 2)
+      if (SLOD_DG(A, 2))
         return;
 #pragma unroll
       for (int ra = 0; ra < R; ++ra)
@@ -196,7 +196,7 @@ namespace
 #pragma unroll
       for (int ka = 0; ka < R; ++ka)
         {
-          const int kend = (A.diag & 4) ? (ka == 0 ? 2 : 0) : min(16, m_even - 16 * ka);
+          const int kend = (SLOD_DG(A, 4)) ? (ka == 0 ? 2 : 0) : min(16, m_even - 16 * ka);
           for (int kt = 0; kt < kend; kt += 2)
             {
               const int k    = 16 * ka + kt;
@@ -213,7 +213,7 @@ namespace
                 continue;
               const double pa = row0[k], pb = row0[k + 1], pc = row1[k + 1];
               const double det = fma(pa, pc, -(pb * pb));
-              if (tid == 0 && !(det > 0.0 && pa > 0.0) && !A.diag)
+              if (tid == 0 && !(det > 0.0 && pa > 0.0) && !SLOD_DG(A, -1))
                 atomicOr(A.status, 1);
               const double idet = fast_rcp(det);
               const double P00 = pc * idet, P01 = -pb * idet, P11 = pa * idet;
@@ -272,7 +272,7 @@ namespace
               {
                 const double v  = -a[ra][rb];
                 Vs[i * ldv + j] = v;
-                if (!(A.diag & 32))
+                if (!(SLOD_DG(A, 32)))
                   vl[i * mm + j] = v;
               }
           }
@@ -347,10 +347,10 @@ namespace
         double u[R][R];
         if (active)
           {
-            if (!(A.diag & 8))
+            if (!(SLOD_DG(A, 8)))
               gemm_store(line, false);
             // U = V Bn replaces V in Vs (only the next Schur update of this chain reads it)
-            if (!(A.diag & 1))
+            if (!(SLOD_DG(A, 1)))
               {
 #pragma unroll
                 for (int rb = 0; rb < R; ++rb)
@@ -383,7 +383,7 @@ namespace
               }
           }
         __syncthreads(); // every read of V (GEMM, U tiles) is done
-        if (active && !(A.diag & 1))
+        if (active && !(SLOD_DG(A, 1)))
           {
 #pragma unroll
             for (int ra = 0; ra < R; ++ra)
@@ -489,9 +489,9 @@ namespace
             vpre[ra][rb] = (i < m && j < m) ? vl[i * mm + j] : 0.0;
           }
     };
-    if (nmy > 0 && !(A.diag & 16))
+    if (nmy > 0 && !(SLOD_DG(A, 16)))
       prefetch_V(chain == 0 ? nmy - 1 : L - nmy);
-    for (int t = (A.diag & 16) ? -1 : nstp - 1; t >= 0; --t)
+    for (int t = (SLOD_DG(A, 16)) ? -1 : nstp - 1; t >= 0; --t)
       {
         const bool active = t < nmy;
         const int  line   = chain == 0 ? t : L - 1 - t;
@@ -564,7 +564,7 @@ static hipError_t launch_solve_RST(const SlodKernelArgs &a, int n_patches, size_
   hipError_t  e  = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess)
     return e;
-  if (getenv("SLOD_DEBUG"))
+  if (a.debug)
     {
       int nb = 0;
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256 * (TW + 1), lds);

@@ -55,7 +55,7 @@ namespace
     const int dl  = chain == 0 ? 1 : -1;
     auto      line_of = [&](int c, int t) { return c == 0 ? t : L - 1 - t; }; // t == n_c gives mid
 
-    if ((A.diag & (1 << 20)) && tid == 0)
+    if ((SLOD_DG(A, (1 << 20))) && tid == 0)
       A.ms[(size_t)blockIdx.x * A.nc_max * A.nc_max] = (double)wall_clock64();
     // Fused stencil assembly: the workgroup builds the stencil planes of its own patch (k_assemble
     // as a device function), saving a launch and its tail; the planes still go through the
@@ -176,7 +176,7 @@ namespace
               for (int a0 = 0; a0 < T; ++a0)
                 {
                   const int k = T * ka + a0;
-                  if (k >= m || ((A.diag & 4) && k > 0)) // wave-uniform
+                  if (k >= m || ((SLOD_DG(A, 4)) && k > 0)) // wave-uniform
                     continue;
                   if (gy == ka)
                     {
@@ -246,11 +246,11 @@ namespace
             if (active)
               {
                 sweep();
-                if (!(A.diag & 32768))
+                if (!(SLOD_DG(A, 32768)))
                   store_tile(vg + (size_t)line_of(chain, t) * vline, -1.0);
                 // Schur complement of the next line (the meeting line after the last step), in
                 // registers: overlaps the drain of the V stores before the barrier
-                if (!(A.diag & 16384))
+                if (!(SLOD_DG(A, 16384)))
                   next_S((t & 1) ? Tn1 : Tn0, Bbuf(Bc0, t));
               }
             __syncthreads(); // A_t: V of step t is in the workspace, bands of step t+1 are in LDS
@@ -270,7 +270,7 @@ namespace
             sweep();
             store_tile(vg + (size_t)mid * vline, -1.0);
           }
-        if (bad && lane == 0 && !A.diag)
+        if (bad && lane == 0 && !SLOD_DG(A, -1))
           atomicOr(A.status, 1);
         __builtin_amdgcn_s_setprio(0);
         __syncthreads(); // M2: V_mid is in the workspace
@@ -284,7 +284,7 @@ namespace
         // rows with a sliding window of Z(prev)[p][r], p = i-W..i+W: one coalesced workspace load
         // per row instead of 2W+1 gathers, and the loads do not depend on the arithmetic.
         auto build_R = [&](int line, const double *Bprev, const double *zprev, bool with_F, bool add) __attribute__((always_inline)) {
-          if (A.diag & 2)
+          if (SLOD_DG(A, 2))
             return;
           const int half = lane >> 5, i_lo = half ? (m + 1) / 2 : 0, i_hi = half ? m : (m + 1) / 2;
           for (int r = lane & 31; r < nc; r += 32)
@@ -329,7 +329,7 @@ namespace
         const int tiles_i = (m + 15) >> 4, tiles_j = (nc + 15) >> 4;
         // Z(line) = V(line) Rb -> workspace; A operand straight from the workspace (rows clamped)
         auto gemm_Z = [&](int line) __attribute__((always_inline)) {
-          if (A.diag & 8)
+          if (SLOD_DG(A, 8))
             return;
           const double *vl = vg + (size_t)line * vline;
           double       *xl = xg + (size_t)line * xline;
@@ -388,7 +388,7 @@ namespace
                 __builtin_amdgcn_wave_barrier();
                 gemm_Z(line);
               }
-            if (t > 0 && !(A.diag & 32))
+            if (t > 0 && !(SLOD_DG(A, 32)))
               put_step(t + 1, lane, 64); // bands the GJ wave needs after its next sweep
             __syncthreads(); // A_t
           }
@@ -447,7 +447,7 @@ namespace
               Bdst[(i + W) * BWP + oi] = bv[q];
           }
       };
-      const int tstart = (A.diag & 16) ? -1 : nstp - 1;
+      const int tstart = (SLOD_DG(A, 16)) ? -1 : nstp - 1;
       if (tstart >= 0 && tstart < nmy)
         {
           fetch_B(line_of(chain, tstart));
@@ -541,7 +541,7 @@ namespace
     // least squares, phi and psi of its patch (X is fresh in this CU's L2 slice).  Patches of
     // different shapes then balance inside ONE launch: rim patches are quick to solve and slow
     // to select (SVD fallback), full patches the other way round.
-    const bool stamp = (A.diag & (1 << 20)) && tid == 0; // per-patch timeline (100 MHz clock) into ms
+    const bool stamp = (SLOD_DG(A, (1 << 20))) && tid == 0; // per-patch timeline (100 MHz clock) into ms
     if (stamp)
       A.ms[(size_t)blockIdx.x * A.nc_max * A.nc_max + 1] = (double)wall_clock64();
     if (S == 1 && A.fuse_select)
@@ -572,7 +572,7 @@ static hipError_t launch_tw_TS(const SlodKernelArgs &a, int n_patches, size_t ld
   hipError_t  e  = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess)
     return e;
-  if (getenv("SLOD_DEBUG"))
+  if (a.debug)
     {
       int nb = 0;
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, lds);

@@ -172,7 +172,7 @@ namespace
               for (int a0 = 0; a0 < T; ++a0)
                 {
                   const int k = T * ka + a0;
-                  if (k < k0 || k >= k1 || ((A.diag & 4) && k > 0)) // wave-uniform
+                  if (k < k0 || k >= k1 || ((SLOD_DG(A, 4)) && k > 0)) // wave-uniform
                     continue;
                   if (gy == ka)
                     {
@@ -250,13 +250,13 @@ namespace
             if (l > 0 && A.m_fused)
               __syncthreads(); // D_{l-1}
             sweep(ksplit2, m);
-            if (bad && lane == 0 && !A.diag)
+            if (bad && lane == 0 && !SLOD_DG(A, -1))
               atomicOr(A.status, 1);
             __syncthreads(); // B'_l
-            if (!(A.diag & 32768))
+            if (!(SLOD_DG(A, 32768)))
               store_V(l);
             __syncthreads(); // A_l
-            if (l + 1 < L && !(A.diag & 16384))
+            if (l + 1 < L && !(SLOD_DG(A, 16384)))
               next_S(Tn, (l & 1) ? Bc1 : Bc0);
           }
         __builtin_amdgcn_s_setprio(0);
@@ -273,7 +273,7 @@ namespace
         // R_l = F_l - B_{l-1}^T Z_{l-1}; F = rows of P^T (LOD.cc:478-495)
         auto build_R = [&](int l) __attribute__((always_inline)) {
           const double *Bprev = (l & 1) ? Bc0 : Bc1; // coupling l-1 -> l
-          for (int i = hr; i < ((A.diag & 2) ? 0 : m); i += 6)
+          for (int i = hr; i < ((SLOD_DG(A, 2)) ? 0 : m); i += 6)
             {
               const int pos = i / S, comp = i - pos * S;
               const int ix = tr ? l + 1 : pos + 1, iy = tr ? pos + 1 : l + 1;
@@ -305,7 +305,7 @@ namespace
         // Z_l = V_l R_l -> Zp, workspace; 16x16 output tiles dealt to the three helper waves
         const int k4 = (m + 3) & ~3, tiles_i = (m + 15) >> 4, tiles_j = (nc + 15) >> 4;
         auto gemm_Z = [&](int l) __attribute__((always_inline)) {
-          if (A.diag & 8)
+          if (SLOD_DG(A, 8))
             return;
           double *xl = xg + (size_t)l * xline;
           for (int t = wave - 1; t < tiles_i * tiles_j; t += 3)
@@ -360,7 +360,7 @@ namespace
             {
               const int idx = hid + 192 * q;
               const int i = idx / BW, o = idx - i * BW - W;
-              const bool in = idx < m * BW && !(A.diag & 32);
+              const bool in = idx < m * BW && !(SLOD_DG(A, 32));
               tband[q] = (in && l + 1 < L) ? coupling<S>(st, A.nn_max, npx, tr, m, l + 1, i, 0, o) : 0.0;
               bband[q] = (in && l + 1 < L) ? coupling<S>(st, A.nn_max, npx, tr, m, l, i, 1, o) : 0.0;
             }
@@ -432,9 +432,9 @@ namespace
           vpre[q]       = (idx < m * m) ? vl[(idx / m) * MP + (idx % m)] : 0.0;
         }
     };
-    if (L >= 2 && !(A.diag & 16))
+    if (L >= 2 && !(SLOD_DG(A, 16)))
       prefetch_V(L - 2);
-    for (int l = (A.diag & 16) ? -1 : L - 2; l >= 0; --l)
+    for (int l = (SLOD_DG(A, 16)) ? -1 : L - 2; l >= 0; --l)
       {
         double *Bn = Bc0;
         load_bands(l, nullptr, Bn, tid, 256);
@@ -524,7 +524,7 @@ static hipError_t launch_ws_TS(const SlodKernelArgs &a, int n_patches, size_t ld
   hipError_t  e  = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess)
     return e;
-  if (getenv("SLOD_DEBUG"))
+  if (a.debug)
     {
       int nb = 0;
       (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, lds);

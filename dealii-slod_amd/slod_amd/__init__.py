@@ -34,6 +34,12 @@ class PatchInfo(C.Structure):
                 ("n_boundary", C.c_int32), ("n_coarse", C.c_int32), ("is_lod", C.c_int32)]
 
 
+class PatchDiag(C.Structure):
+    """slod_patch_diag: decisions of the SLOD selection stage for one (patch, component)."""
+    _fields_ = [("path", C.c_int32), ("n_cut", C.c_int32), ("n_dropped", C.c_int32), ("sweeps", C.c_int32),
+                ("dinf", C.c_double), ("sigma_max", C.c_double), ("sigma_min", C.c_double)]
+
+
 _lib = None
 
 
@@ -79,6 +85,7 @@ def load():
     lib.slod_plan_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.slod_plan_profile.argtypes = [vp, C.c_int]
     lib.slod_plan_status.argtypes = [vp]
+    lib.slod_plan_diagnostics.argtypes = [vp, C.POINTER(PatchDiag), C.c_size_t]
     lib.slod_compute_basis.argtypes = [vp, u32p, C.c_size_t, dp, dp, u64p]
     lib.slod_assemble_stiffness_for_patch.argtypes = [vp, C.c_uint32, dp]
     lib.slod_patch_solution.argtypes = [vp, C.c_uint32, dp]
@@ -135,6 +142,15 @@ class Plan:
 
     def status(self):
         self.slod._check(self.lib.slod_plan_status(self.p))
+
+    def diagnostics(self):
+        """[(patch k, component d)] -> PatchDiag of the last execute."""
+        n = len(self.gids) * self.slod.spacedim
+        buf = (PatchDiag * max(n, 1))()
+        rc = self.lib.slod_plan_diagnostics(self.p, buf, n)
+        if rc < 0:
+            self.slod._check(rc)
+        return [buf[i] for i in range(n)]
 
     def close(self):
         if self.p:

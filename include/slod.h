@@ -17,7 +17,10 @@
  * (never throws across the ABI; slod_last_error() gives the text -- the reference throws
  * deal.II exceptions instead, LODtools.h:416-438).  Caller owns every buffer it passes;
  * the library owns its device workspace.  A handle is thread-compatible (one thread at a
- * time), like the reference's non-re-entrant patch loop (LOD.cc:302-322).
+ * time), like the reference's non-re-entrant patch loop (LOD.cc:302-322).  A plan owns ONE
+ * workspace and ONE status word: executes of the same plan must not overlap (enqueue them on
+ * one stream, or wait for the previous one); different plans of a handle may run concurrently
+ * on different streams.
  *
  * Vector layout: per patch, PATCH-LEXICOGRAPHIC node order, component-minor:
  *     dof = spacedim*(ix + iy*(nx+1)) + comp,  ix in [0,nx], iy in [0,ny], nx = n_sub*mx.
@@ -34,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SLOD_ABI_VERSION 1
+#define SLOD_ABI_VERSION 2
 
 typedef enum
 {
@@ -133,6 +136,25 @@ int slod_plan_profile(slod_plan *p, int depth);
 int slod_plan_kernel_ms(slod_plan *p, float ms[3]);
 /* numerical status of the last execute (0 or SLOD_ERR_NUMERIC); synchronises. */
 int slod_plan_status(slod_plan *p);
+
+/* Decisions the SLOD selection stage took for one (patch, component): the discontinuous part
+ * of LOD.cc:656-725 (pseudo-inverse cutoff :667, "drop the smallest triplet while
+ * ||d||_inf >= 0.5" :703-725).  Parity tests assert them equal to the CPU oracle's. */
+typedef struct
+{
+  int32_t path;       /* 0 = LOD branch (LOD.cc:566-595); 1 = SLOD, proven decision-free (QR:
+                         no singular value near the cutoff, ||d||_inf < 0.5); 2 = SLOD, loop
+                         replayed on the singular triplets                                     */
+  int32_t n_cut;      /* singular values of G = BD'^T BD' with sigma <= 1e-15 sigma_0 (:667)   */
+  int32_t n_dropped;  /* triplets put back by the 0.5-loop (:703-725)                          */
+  int32_t sweeps;     /* Jacobi sweeps of the replay (path 2)                                  */
+  double  dinf;       /* final ||d||_inf                                                       */
+  double  sigma_max, sigma_min; /* extreme singular values of G (path 2; 0 otherwise)          */
+} slod_patch_diag;
+/* out[k*spacedim + d] for patch k of the plan, component d, of the LAST execute; HOST buffer of
+ * `capacity` entries.  Returns the number of entries written or a negative slod_status;
+ * synchronises. */
+int slod_plan_diagnostics(slod_plan *p, slod_patch_diag *out, size_t capacity);
 
 /* Host-buffer convenience wrapper: plan + execute + copy back (what the deal.II adapter
  * calls).  basis/premult are HOST pointers. */

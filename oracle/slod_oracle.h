@@ -111,6 +111,9 @@ void so_patch_pt(const so_cfg *cfg, int pid, double *PT);
 /* 0 (default): one-sided Jacobi SVD of BD'; 1: literal Gram matrix G = BD'^T BD' +
  * Jacobi eigen-solver (LOD.cc:660-667 with dgesdd replaced). */
 void so_set_svd_mode(int mode);
+/* conditioning probe for the parity tests: relative noise eps on X before the selection stage
+ * (0 = off); see slod_oracle.c */
+void so_set_solver_noise(double eps, unsigned long long seed);
 
 /* ---- synthetic coefficient fields ---------------------------------------- */
 /* splitmix64 stream, one value per fine ELEMENT (row-major, ex fastest), broadcast to

@@ -65,6 +65,7 @@ def lib():
         _lib.so_num_patches.argtypes = [C.POINTER(Cfg)]
         _lib.so_set_svd_mode.argtypes = [C.c_int]
         _lib.so_patch_pt.argtypes = [C.POINTER(Cfg), C.c_int, dp]
+        _lib.so_set_solver_noise.argtypes = [C.c_double, C.c_ulonglong]
     return _lib
 
 
@@ -207,6 +208,28 @@ def fe_q_iso_q1_cell_matrix(dim, n):
 
 def set_svd_mode(mode):
     lib().so_set_svd_mode(mode)
+
+
+def set_solver_noise(eps, seed=0):
+    """Conditioning probe: relative noise eps on X before the selection stage (0 = off)."""
+    lib().so_set_solver_noise(eps, seed)
+
+
+def selection_conditioning(cfg, coefs, pid, eps=1e-13):
+    """How far phi and the decisions of patch `pid` move when X carries the rounding noise of
+    another fp64 solver (two noise draws).  -> (max |dphi|, decisions_stable)."""
+    phi0, _, d0 = patch_basis(cfg, coefs, pid)
+    spread, stable = 0.0, True
+    try:
+        for seed in (1, 2):
+            set_solver_noise(eps, seed)
+            phi1, _, d1 = patch_basis(cfg, coefs, pid)
+            spread = max(spread, float(np.abs(phi1 - phi0).max()))
+            for c in range(cfg.spacedim):
+                stable = stable and d1.n_cut[c] == d0.n_cut[c] and d1.n_dropped[c] == d0.n_dropped[c]
+    finally:
+        set_solver_noise(0.0, 0)
+    return spread, stable
 
 
 def patch_pt(cfg, pid):

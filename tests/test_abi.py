@@ -16,7 +16,20 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 18
     for n in names:
         assert hasattr(lib, n), "missing export " + n
-    assert lib.slod_abi_version() == 1
+    assert lib.slod_abi_version() == 2
+
+
+def test_release_library_exports_exactly_the_header():
+    """The release .so exports include/slod.h and nothing else: no timing-experiment hooks
+    (slod_debug_read_ms lives only in lib/libslod_hip_diag.so, built with -DSLOD_ENABLE_DIAG)."""
+    import subprocess
+    import slod_amd
+    out = subprocess.check_output(["nm", "-D", "--defined-only", slod_amd.LIB_PATH], text=True)
+    exported = sorted(ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("slod_"))
+    assert exported == slod_amd.declared_symbols()
+    # and the phase-skip environment variable is not even referenced by the release binary
+    blob = open(slod_amd.LIB_PATH, "rb").read()
+    assert b"SLOD_DIAG" not in blob
 
 
 def test_create_rejects_bad_config():
