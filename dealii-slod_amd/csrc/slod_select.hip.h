@@ -889,9 +889,12 @@ namespace
                 for (int idx = tid; idx < nn1 * nn1; idx += 256)
                   Vj[idx] = ((idx / nn1) == (idx % nn1)) ? 1.0 : 0.0;
                 // Frobenius norm^2 (rotation invariant): columns below 1e-22 of it are numerically
-                // zero -- seven orders under the reference's 1e-15 cutoff on sigma(G) -- and are
-                // not rotated (two noise columns never pass the relative test and would keep
-                // every sweep busy on rank-deficient rim patches)
+                // zero -- seven orders under the reference's 1e-15 cutoff on sigma(G).  A pair of
+                // two such noise columns is not rotated (it never passes the relative test and would
+                // keep every sweep busy on rank-deficient rim patches); a noise column IS rotated
+                // against a live one: skipping that pair leaves the live column's direction off by
+                // |noise|^2/|live|^2 (up to 1e-7 for a triplet just above the cutoff), which
+                // oversampling-3 corner patches amplified to 1e-6 .. 1e-4 in phi
                 double fro = 0.0;
                 for (int idx = tid; idx < wr * nn1; idx += 256)
                   {
@@ -944,7 +947,7 @@ namespace
                                 aqq += dpp_rot<0x4E>(aqq);
                                 apq += dpp_rot<0x4E>(apq);
                                 const bool rot = valid && !(apq == 0.0 || apq * apq <= 1e-30 * (app * aqq) ||
-                                                            fmin(app, aqq) <= tiny);
+                                                            fmax(app, aqq) <= tiny);
                                 if (rot)
                                   {
                                     const double dd = aqq - app;
@@ -1011,7 +1014,7 @@ namespace
                               app = group16_sum(app);
                               aqq = group16_sum(aqq);
                               apq = group16_sum(apq);
-                              if (apq == 0.0 || apq * apq <= 1e-30 * (app * aqq) || fmin(app, aqq) <= tiny)
+                              if (apq == 0.0 || apq * apq <= 1e-30 * (app * aqq) || fmax(app, aqq) <= tiny)
                                 continue;
                               // t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (aqq-app)/(2 apq),
                               // written without the division by apq; c = 1/sqrt(1+t^2), s = c t

@@ -1,5 +1,839 @@
-// k_solve_mf: placeholder until the MFMA-factorised kernel lands (never chosen: 0 tiles).
-#include "slod_device.h"
-int        slod_solve_mf_tiles(int, int) { return 0; }
-size_t     slod_solve_mf_lds_bytes(int, int, int) { return ~(size_t)0; }
-hipError_t slod_launch_solve_mf(int, const SlodKernelArgs &, int, size_t, hipStream_t) { return hipErrorInvalidValue; }
+// k_solve_mf: twisted block-tridiagonal patch solve, Gauss-Jordan on the fp64 matrix pipe (default).
+#include "slod_assemble.hip.h"
+#include "slod_select.hip.h"
+
+namespace
+{
+  // ---------------------------------------------------------------------------------
+  // K2 (MFMA-factorised).  Same elimination as k_solve_tw -- two chains per patch that meet at
+  // line mid, V_l = S_l^-1 explicit so that both right-hand-side sweeps are GEMMs -- but the
+  // inversion itself runs on the matrix pipe:
+  //   * the Gauss-Jordan wave of a chain keeps S_l as NT x NT tiles of 16 x 16 in the
+  //     v_mfma_f64_16x16x4_f64 accumulator layout (lane (g,c) = (l>>4, l&15), register r:
+  //     entry (16 ti + 4 r + g, 16 tj + c)) and sweeps FOUR pivots per step: the pivot rows
+  //     K = {4 kb .. 4 kb + 3} are register r = kb & 3 of tile row kb >> 2 -- already the B operand
+  //     C[K,:] of the rank-4 update, and by symmetry also its A operand C[:,K]^T.  Only
+  //     W = C_KK^-1 (4 x 4, solved per lane for its own row) has to be folded in, which needs the
+  //     panel once through a wave-private LDS line: U = -(C[:,K] W), then
+  //     C <- C + U * C[K,:] is NT^2 MFMAs, the pivot rows are overwritten by W C[K,:] and -W.
+  //     One LDS round trip and ~100 VALU instructions per 4 pivots instead of ~95 per pivot.
+  //   * the next Schur complement T - B^T V B (B banded) stays in registers: the column mixing
+  //     V B uses DPP lane shifts inside the 16-lane rows, the row mixing B^T (V B) a small LDS
+  //     window of one tile row.
+  //   * right-hand sides are independent per column: a helper wave (forward) / every wave
+  //     (backward) owns 16-column tiles of Z/X, keeps them in the accumulator layout -- which is
+  //     the B operand layout of the next product -- and needs no workgroup barrier in the
+  //     backward sweep at all.
+  // V is stored per line as NT x NT accumulator tiles (512-byte coalesced stores); by symmetry
+  // tile (kk >> 2, ti), register kk & 3 IS the A operand V[16 ti + c][4 kk + g] of the GEMMs.
+  // The patch matrix is scaled by a power of two so that its entries are <= 1: the sweep mixes
+  // C with the identity (C_KK - I in the column update), harmless only at that scale.
+  // ---------------------------------------------------------------------------------
+  __host__ __device__ constexpr int mf_min_waves(int NT, int S) { return NT <= 4 ? 2 : 1; }
+
+  typedef double double2_t __attribute__((ext_vector_type(2)));
+
+  // lanes whose DPP source is inside the row take it, the others keep `old`
+  template <int CTRL>
+  __device__ __forceinline__ double dpp_upd(double old, double v)
+  {
+    union
+    {
+      double d;
+      int    i[2];
+    } o, in, out;
+    o.d      = old;
+    in.d     = v;
+    out.i[0] = __builtin_amdgcn_update_dpp(o.i[0], in.i[0], CTRL, 0xf, 0xf, false);
+    out.i[1] = __builtin_amdgcn_update_dpp(o.i[1], in.i[1], CTRL, 0xf, 0xf, false);
+    return out.d;
+  }
+  // value of column j - w / j + w of a tile row: inside the tile from lane c -+ w (row_shr / row_shl),
+  // across the tile edge from the neighbouring tile's register (row_ror)
+  template <int w>
+  __device__ __forceinline__ double col_left(double cur, double prev_tile)
+  {
+    return dpp_upd<0x110 + w>(dpp_rot<0x120 + w>(prev_tile), cur);
+  }
+  template <int w>
+  __device__ __forceinline__ double col_right(double cur, double next_tile)
+  {
+    return dpp_upd<0x100 + w>(dpp_rot<0x120 + 16 - w>(next_tile), cur);
+  }
+
+#define SLOD_WAVE_SYNC()                                        \
+  do                                                            \
+    {                                                           \
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
+      __builtin_amdgcn_wave_barrier();                          \
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
+    }                                                           \
+  while (0)
+
+  template <int NT, int S>
+  __global__ __launch_bounds__(256, mf_min_waves(NT, S)) void k_solve_mf(const SlodKernelArgs A)
+  {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const SlodPatchDesc d = A.desc[blockIdx.x];
+    constexpr int       W = 2 * S - 1, BW = 2 * W + 1, MP = 16 * NT, NB = MP / 4;
+    constexpr int       BWP = BW + 1, BROWS = MP + 2 * W, bsz = (BROWS * BWP + 1) & ~1;
+    constexpr int       PST = MP + 2;          // panel row stride (even: 16-byte aligned pivot block)
+    constexpr int       WST = MP + 1, WROWS = 16 + 2 * W; // row-mixing window
+    constexpr int       XST = 17;              // backward strips: [MP + 2 W][16 + 1]
+    constexpr int       chsz = (4 * PST + WROWS * WST + 6 * bsz + 1) & ~1; // doubles per chain
+    const int           tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int           chain = wave & 1;
+    const bool          is_gj = wave < 2;
+    const int           g = lane >> 4, c = lane & 15;
+    const int           m = d.m, L = d.L, nc = d.n_c, n = A.n_sub;
+    const int           mm = A.m_max, ncg = A.nc_max;
+    const int           nct = (nc + 15) >> 4, npass = (nct + 1) >> 1;
+    const bool          tr  = (d.flags & SLOD_F_TRANSPOSED) != 0;
+    const int           npx = d.nx + 1;
+
+    double *cb    = smem + chain * chsz;
+    double *panel = cb;                  // [4][PST]      pivot rows of the current block step
+    double *ywin  = panel + 4 * PST;     // [WROWS][WST]  one tile row of V B (+ halo rows)
+    double *Tf    = ywin + WROWS * WST;  // padded bands: T of the chain's first line,
+    double *Tn0   = Tf + bsz;            //   T bands of the steps (by step parity),
+    double *Tn1   = Tn0 + bsz;
+    double *Bc0   = Tn1 + bsz;           //   coupling bands of the steps (by step mod 3)
+    auto    Bbuf  = [&](double *base, int stp) { return base + ((stp + 3) % 3) * bsz; };
+    double *ocb   = smem + (1 - chain) * chsz;
+    int    *colk  = reinterpret_cast<int *>(smem + 2 * chsz); // [2][nc_max]
+
+    const double *st    = A.st + (size_t)blockIdx.x * A.st_stride;
+    double       *vg    = A.vinv + (size_t)blockIdx.x * A.v_stride;
+    double       *xg    = A.xs + (size_t)blockIdx.x * A.x_stride;
+    const size_t  vline = (size_t)MP * MP, xline = (size_t)mm * ncg;
+
+    const int mid = L / 2;
+    const int n0 = mid, n1 = L - 1 - mid, nstp = n0 > n1 ? n0 : n1;
+    const int nmy = chain == 0 ? n0 : n1; // lines of this chain
+    const int dl  = chain == 0 ? 1 : -1;
+    auto      line_of = [&](int ch, int t) { return ch == 0 ? t : L - 1 - t; }; // t == n_ch gives mid
+
+    if (SLOD_DG(A, (1 << 20)) && tid == 0)
+      A.ms[(size_t)blockIdx.x * A.nc_max * A.nc_max] = (double)wall_clock64();
+    // fused stencil assembly (scalar problems): the workgroup builds the planes of its own patch
+    if (S == 1 && A.fuse_assemble)
+      {
+        for (int node = tid; node < npx * (d.ny + 1); node += 256)
+          assemble_node<S>(A, d, blockIdx.x, node);
+      }
+    for (int idx = tid; idx < 2 * chsz; idx += 256)
+      smem[idx] = 0.0;
+    for (int cc = tid; cc < nc; cc += 256)
+      {
+        int kx, ky;
+        cell_of_col(d, cc / S, kx, ky);
+        colk[cc]            = kx;
+        colk[A.nc_max + cc] = ky;
+      }
+    __syncthreads();
+    // power-of-two scale: the largest diagonal stencil entry of the patch becomes < 1
+    double sc = 1.0;
+    {
+      double dmx = 0.0;
+      for (int node = tid; node < npx * (d.ny + 1); node += 256)
+#pragma unroll
+        for (int a = 0; a < S; ++a)
+          dmx = fmax(dmx, st[(size_t)((4 * S + a) * S + a) * A.nn_max + node]);
+      for (int off = 32; off > 0; off >>= 1)
+        dmx = fmax(dmx, __shfl_xor(dmx, off, 64));
+      if (lane == 0)
+        smem[wave] = dmx; // panel of chain 0: not yet in use
+      __syncthreads();
+      dmx = fmax(fmax(smem[0], smem[1]), fmax(smem[2], smem[3]));
+      __syncthreads();
+      if (dmx > 0.0 && dmx < 1e300)
+        {
+          int e;
+          (void)frexp(dmx, &e);
+          sc = ldexp(1.0, -e);
+        }
+      if (tid < 4)
+        smem[tid] = 0.0;
+    }
+    const double scF = A.scale * sc;
+    // write the (zero padded) bands of `line`, scaled: T (within the line; zero band if !with_T)
+    // and the coupling line -> line + dl of this chain; t0/nt = caller's thread slice
+    auto put_bands = [&](int line, double *Tdst, bool with_T, double *Bdst, int t0, int nt) __attribute__((always_inline)) {
+      for (int idx = t0; idx < m * BW; idx += nt)
+        {
+          const int i = idx / BW, oi = idx - i * BW, o = oi - W;
+          if (Tdst)
+            Tdst[(i + W) * BWP + oi] = with_T ? sc * coupling<S>(st, A.nn_max, npx, tr, m, line, i, 0, o) : 0.0;
+          if (Bdst)
+            Bdst[(i + W) * BWP + oi] = sc * coupling<S>(st, A.nn_max, npx, tr, m, line, i, dl, o);
+        }
+    };
+    // Band schedule (as in k_solve_tw): right after the sweep of step t the chain's GJ wave needs
+    // T of line(t+1) (zero for chain 1's meeting line, whose T is added by chain 0) in the T
+    // buffer of parity t, and the coupling line(t) -> line(t+1) in the B buffer t mod 3; they are
+    // written one step ahead: steps 0 and 1 here, step t+1 by the helper during step t.
+    auto put_step = [&](int stp, int t0, int nt) __attribute__((always_inline)) {
+      if (stp >= nmy)
+        return;
+      put_bands(line_of(chain, stp + 1), (stp & 1) ? Tn1 : Tn0, !(chain == 1 && stp + 1 == nmy), nullptr, t0, nt);
+      put_bands(line_of(chain, stp), nullptr, true, Bbuf(Bc0, stp), t0, nt);
+    };
+    {
+      const int t0 = (wave >> 1) * 64 + lane;
+      put_bands(line_of(chain, 0), Tf, true, nullptr, t0, 128);
+      put_step(0, t0, 128);
+      put_step(1, t0, 128);
+    }
+    __syncthreads();
+
+    // ------------------------------ forward elimination ---------------------------
+    if (is_gj)
+      {
+        __builtin_amdgcn_s_setprio(3);
+        double4_t    acc[NT][NT];
+        const int    c3  = c & 3;
+        const double dlt = (g == c3) ? 1.0 : 0.0;
+        double       eg[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          eg[k] = (g == k) ? 1.0 : 0.0;
+        bool bad = false;
+        // entry (16 ti + 4 r + g, 16 tj + c) of a padded T band buffer, |ti - tj| <= 1: offset
+        // 16 ti BWP + toff[tj - ti + 1][r]; column BW of a band row is a zero pad
+        int  toff[3][4];
+        bool isd[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          {
+            const int rho = 4 * r + g;
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt)
+              {
+                const unsigned oi = (unsigned)(c + 16 * (dt - 1) - rho + W);
+                toff[dt][r]       = (rho + W) * BWP + (int)(oi < (unsigned)BW ? oi : (unsigned)BW);
+              }
+            isd[r] = rho == c;
+          }
+        auto t_entry = [&](const double *Tsrc, int ti, int tj, int r, bool pad_identity) __attribute__((always_inline)) {
+          double v = 0.0;
+          if (tj - ti <= 1 && ti - tj <= 1)
+            {
+              v = Tsrc[16 * ti * BWP + toff[tj - ti + 1][r]];
+              if (ti == tj && pad_identity)
+                v = (isd[r] && 16 * ti + c >= m) ? 1.0 : v; // identity on the padding diagonal
+            }
+          return v;
+        };
+
+        // acc <- bands of T (zero outside the band), identity on the padding diagonal
+        auto t_init = [&](const double *Tsrc, bool pad_identity) __attribute__((always_inline)) {
+#pragma unroll
+          for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                acc[ti][tj][r] = t_entry(Tsrc, ti, tj, r, pad_identity);
+        };
+
+        // blocked symmetric sweep of all pivots < m: acc <- -S^-1 (padding: -1 / identity, decoupled)
+        auto sweep = [&]() __attribute__((always_inline)) {
+#pragma unroll
+          for (int kb = 0; kb < NB; ++kb)
+            {
+              if (4 * kb >= m || (SLOD_DG(A, 4) && kb > 0)) // wave-uniform
+                continue;
+              const int  tk = kb >> 2, q = kb & 3;
+              const bool inK = (c >> 2) == q;
+              // pivot rows -> panel (they are the B operand C[K,:] already)
+              double vt[NT];
+#pragma unroll
+              for (int tj = 0; tj < NT; ++tj)
+                {
+                  vt[tj]                          = acc[tk][tj][q];
+                  panel[g * PST + 16 * tj + c] = vt[tj];
+                }
+              SLOD_WAVE_SYNC();
+              // pivot block (uniform addresses), upper triangle
+              const double2_t *pb  = reinterpret_cast<const double2_t *>(panel + 16 * tk + 4 * q);
+              const double2_t  r00 = pb[0], r01 = pb[1];
+              const double2_t  r10 = pb[PST / 2], r11 = pb[PST / 2 + 1];
+              const double2_t  r21 = pb[PST + 1];
+              const double2_t  r31 = pb[3 * (PST / 2) + 1];
+              const double     a00 = r00.x, a01 = r00.y, a02 = r01.x, a03 = r01.y;
+              const double     a11 = r10.y, a12 = r11.x, a13 = r11.y;
+              const double     a22 = r21.x, a23 = r21.y, a33 = r31.y;
+              // panel columns of this lane: C[K_k][16 ti + c]
+              double pc[NT][4];
+#pragma unroll
+              for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                  pc[ti][k] = panel[k * PST + 16 * ti + c];
+              // C_KK = L D L^T, then row g of W = C_KK^-1: solve C_KK w = e_g
+              bad |= !(a00 > 0.0);
+              const double p0  = fast_rcp(a00);
+              const double l10 = a01 * p0, l20 = a02 * p0, l30 = a03 * p0;
+              const double b11 = fma(-l10, a01, a11), b21 = fma(-l20, a01, a12), b31 = fma(-l30, a01, a13);
+              const double b22 = fma(-l20, a02, a22), b32 = fma(-l30, a02, a23), b33 = fma(-l30, a03, a33);
+              bad |= !(b11 > 0.0);
+              const double p1  = fast_rcp(b11);
+              const double l21 = b21 * p1, l31 = b31 * p1;
+              const double c22 = fma(-l21, b21, b22), c32 = fma(-l31, b21, b32), c33 = fma(-l31, b31, b33);
+              bad |= !(c22 > 0.0);
+              const double p2  = fast_rcp(c22);
+              const double l32 = c32 * p2;
+              const double d33 = fma(-l32, c32, c33);
+              bad |= !(d33 > 0.0);
+              const double p3 = fast_rcp(d33);
+              // forward (L y = e_g), scale (D), backward (L^T w = z)
+              const double y0 = eg[0];
+              const double y1 = fma(-l10, y0, eg[1]);
+              const double y2 = fma(-l21, y1, fma(-l20, y0, eg[2]));
+              const double y3 = fma(-l32, y2, fma(-l31, y1, fma(-l30, y0, eg[3])));
+              const double w3 = y3 * p3;
+              const double w2 = fma(-l32, w3, y2 * p2);
+              const double w1 = fma(-l31, w3, fma(-l21, w2, y1 * p1));
+              const double w0 = fma(-l30, w3, fma(-l20, w2, fma(-l10, w1, y0 * p0)));
+              // A operand U = -(C[:,K] W): lane (g,c) holds U[16 ti + c][g]
+              double u[NT];
+#pragma unroll
+              for (int ti = 0; ti < NT; ++ti)
+                u[ti] = -fma(w3, pc[ti][3], fma(w2, pc[ti][2], fma(w1, pc[ti][1], w0 * pc[ti][0])));
+              // B operand: C[K,:], with C_KK - I in the pivot columns (so that C[J,K] <- C[J,K] W)
+              vt[tk] -= inK ? dlt : 0.0;
+#pragma unroll
+              for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < NT; ++tj)
+                  acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[ti], vt[tj], acc[ti][tj], 0, 0, 0);
+              // pivot rows: W C[K,:] = -U, and -W in the pivot block
+              const double wsel = c3 == 0 ? w0 : (c3 == 1 ? w1 : (c3 == 2 ? w2 : w3));
+#pragma unroll
+              for (int tj = 0; tj < NT; ++tj)
+                acc[tk][tj][q] = (tj == tk && inK) ? -wsel : -u[tj];
+            }
+        };
+
+        // acc = -V_l  ->  acc = T_next - B^T V_l B = T_next + B^T acc B   (B = coupling l -> l+1)
+        auto next_S = [&](const double *Tsrc, const double *Bl, bool pad_identity) __attribute__((always_inline)) {
+          // stage A, column mixing in registers: Y[i][j] = sum_e acc[i][j + e - W] * B[j + e - W][j]
+#pragma unroll
+          for (int ti = 0; ti < NT; ++ti)
+            {
+              double4_t y[NT];
+#pragma unroll
+              for (int tj = 0; tj < NT; ++tj)
+                {
+                  double cbv[BW];
+#pragma unroll
+                  for (int e = 0; e < BW; ++e)
+                    cbv[e] = Bl[(16 * tj + c + e) * BWP + (2 * W - e)];
+#pragma unroll
+                  for (int r = 0; r < 4; ++r)
+                    {
+                      const double cur = acc[ti][tj][r];
+                      const double pv  = tj > 0 ? acc[ti][tj > 0 ? tj - 1 : 0][r] : 0.0;
+                      const double nx  = tj + 1 < NT ? acc[ti][tj + 1 < NT ? tj + 1 : tj][r] : 0.0;
+                      double       v   = cbv[W] * cur;
+                      v                = fma(cbv[W - 1], col_left<1>(cur, pv), v);
+                      v                = fma(cbv[W + 1], col_right<1>(cur, nx), v);
+                      if (W > 1)
+                        {
+                          v = fma(cbv[W > 1 ? W - 2 : 0], col_left<(W > 1 ? 2 : 1)>(cur, pv), v);
+                          v = fma(cbv[W > 1 ? W + 2 : 0], col_right<(W > 1 ? 2 : 1)>(cur, nx), v);
+                          v = fma(cbv[W > 1 ? W - 3 : 0], col_left<(W > 1 ? 3 : 1)>(cur, pv), v);
+                          v = fma(cbv[W > 1 ? W + 3 : 0], col_right<(W > 1 ? 3 : 1)>(cur, nx), v);
+                        }
+                      y[tj][r] = v;
+                    }
+                }
+#pragma unroll
+              for (int tj = 0; tj < NT; ++tj)
+                acc[ti][tj] = y[tj];
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          // stage B, row mixing through the LDS window, one tile row at a time:
+          // acc[i][j] = T[i][j] + sum_e B[i + e - W][i] * Y[i + e - W][j]
+#pragma unroll
+          for (int ti = 0; ti < NT; ++ti)
+            {
+              // upper halo: the last W rows of the previous tile row (still in the window)
+              for (int x = lane; x < W * WST; x += 64)
+                ywin[x] = ti > 0 ? ywin[16 * WST + x] : 0.0;
+#pragma unroll
+              for (int tj = 0; tj < NT; ++tj)
+                {
+#pragma unroll
+                  for (int r = 0; r < 4; ++r)
+                    ywin[(4 * r + g + W) * WST + 16 * tj + c] = acc[ti][tj][r];
+                  if (g < W) // lower halo: the first W rows of the next tile row
+                    ywin[(16 + W + g) * WST + 16 * tj + c] = ti + 1 < NT ? acc[ti + 1 < NT ? ti + 1 : ti][tj][0] : 0.0;
+                }
+              SLOD_WAVE_SYNC();
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                {
+                  const int i = 16 * ti + 4 * r + g;
+                  double    rb[BW];
+#pragma unroll
+                  for (int e = 0; e < BW; ++e)
+                    rb[e] = Bl[(i + e) * BWP + (2 * W - e)];
+#pragma unroll
+                  for (int tj = 0; tj < NT; ++tj)
+                    {
+                      const int j = 16 * tj + c;
+                      double    v = t_entry(Tsrc, ti, tj, r, pad_identity);
+#pragma unroll
+                      for (int e = 0; e < BW; ++e)
+                        v = fma(rb[e], e == W ? acc[ti][tj][r] : ywin[(4 * r + g + e) * WST + j], v);
+                      acc[ti][tj][r] = v;
+                    }
+                }
+              SLOD_WAVE_SYNC();
+            }
+        };
+
+        // tiles <-> workspace (accumulator layout: 512-byte coalesced per register)
+        auto store_tiles = [&](double *dst, double sign) __attribute__((always_inline)) {
+#pragma unroll
+          for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < NT; ++tj)
+              {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                  (dst + ((ti * NT + tj) * 4 + r) * 64)[lane] = sign * acc[ti][tj][r]; // uniform base + lane
+                __builtin_amdgcn_sched_barrier(0); // one tile at a time: no 36 negated copies in flight
+              }
+        };
+
+        // acc = T of the chain's first line (chain 1 without lines contributes nothing)
+        if (chain == 1 && nmy == 0)
+          {
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+              for (int tj = 0; tj < NT; ++tj)
+                acc[ti][tj] = double4_t{0.0, 0.0, 0.0, 0.0};
+          }
+        else
+          t_init(Tf, true);
+        for (int t = 0; t < nstp; ++t)
+          {
+            if (t < nmy)
+              {
+                sweep();
+                if (!SLOD_DG(A, 32768))
+                  store_tiles(vg + (size_t)line_of(chain, t) * vline, -1.0);
+                // Schur complement of the next line (the meeting line after the last step)
+                if (!SLOD_DG(A, 16384))
+                  next_S((t & 1) ? Tn1 : Tn0, Bbuf(Bc0, t), !(chain == 1 && t + 1 == nmy));
+              }
+            __syncthreads(); // A_t: V of step t is in the workspace, bands of step t+1 are in LDS
+          }
+        // the meeting line: chain 0 holds T_mid - W_0, chain 1 holds -W_1
+        if (chain == 1)
+          store_tiles(vg + (size_t)mid * vline, 1.0);
+        __syncthreads(); // M1: chain 1's contribution is in the workspace
+        if (chain == 0)
+          {
+            const double *w1 = vg + (size_t)mid * vline;
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+              for (int tj = 0; tj < NT; ++tj)
+                {
+#pragma unroll
+                  for (int r = 0; r < 4; ++r)
+                    acc[ti][tj][r] += (w1 + ((ti * NT + tj) * 4 + r) * 64)[lane];
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+            sweep();
+            store_tiles(vg + (size_t)mid * vline, -1.0);
+          }
+        if (bad && lane == 0 && !SLOD_DG(A, -1))
+          atomicOr(A.status, 1);
+        __builtin_amdgcn_s_setprio(0);
+        __syncthreads(); // M2: V_mid is in the workspace
+        __syncthreads(); // M3: X_mid is in the workspace
+      }
+    else
+      {
+        // ===== helper wave of the chain: right-hand sides of the line one step behind =====
+        // B operand of Z = V R for a pair of column tiles: rop[kk][t2] = R[4 kk + g][16 (2 pass + t2) + c],
+        // R = (with_F ? F_line : 0) - Bprev^T Z(prev line) [+ rop]; Z from the workspace
+        // weight of P^T along one coordinate: node offset j inside the cell (0 .. n), else 0
+        auto pw1 = [&](int j) { return (unsigned)j > (unsigned)n ? 0.0 : ((j == 0 || j == n) ? 1.0 : 2.0); };
+        auto build_rop = [&](double (&rop)[NB][2], int pass, int line, const double *Bprev, const double *zprev,
+                             bool with_F, bool add) __attribute__((always_inline)) {
+          int           kA[2], col[2];
+          bool          cok[2];
+          double        wL[2];
+          const double *zc[2];
+#pragma unroll
+          for (int t2 = 0; t2 < 2; ++t2)
+            {
+              col[t2]       = 16 * (2 * pass + t2) + c;
+              cok[t2]       = col[t2] < nc;
+              const int cc  = min(col[t2], nc - 1);
+              const int kxn = colk[cc] * n, kyn = colk[A.nc_max + cc] * n;
+              // scalar problems: F = scale * w(along the line) * w(across); the across factor per line
+              kA[t2] = tr ? kyn : kxn;
+              wL[t2] = scF * pw1(line + 1 - (tr ? kxn : kyn));
+              zc[t2] = zprev ? zprev + cc : nullptr; // clamped column: the result is dropped below
+            }
+#pragma unroll
+          for (int kk = 0; kk < NB; ++kk)
+            {
+              if (4 * kk >= m || SLOD_DG(A, 2)) // wave-uniform
+                {
+                  rop[kk][0] = rop[kk][1] = 0.0;
+                  continue;
+                }
+              const int i = 4 * kk + g;
+              double    bc[BW];
+              int       pe[BW];
+#pragma unroll
+              for (int e = 0; e < BW; ++e)
+                {
+                  bc[e] = Bprev[(i + e) * BWP + (2 * W - e)]; // B[p][i], p = i + e - W; zero band rows outside [0,m)
+                  pe[e] = min(max(i + e - W, 0), m - 1) * ncg;  // clamped row: its coefficient is zero
+                }
+#pragma unroll
+              for (int t2 = 0; t2 < 2; ++t2)
+                {
+                  const bool ok = cok[t2] && i < m;
+                  double     v  = add ? rop[kk][t2] : 0.0;
+                  if (with_F)
+                    {
+                      if (S == 1)
+                        v = fma(wL[t2], pw1(i + 1 - kA[t2]), v);
+                      else
+                        {
+                          const int pos = i / S, comp = i - pos * S;
+                          const int ix = tr ? line + 1 : pos + 1, iy = tr ? pos + 1 : line + 1;
+                          v += scF * pt_weight<S>(d, n, A.quirk, ix, iy, comp, min(col[t2], nc - 1));
+                        }
+                    }
+                  if (zprev)
+                    {
+#pragma unroll
+                      for (int e = 0; e < BW; ++e)
+                        v = fma(-bc[e], zc[t2][pe[e]], v);
+                    }
+                  rop[kk][t2] = ok ? v : 0.0;
+                }
+              if (kk % 3 == 2)
+                __builtin_amdgcn_sched_barrier(0); // bounds the loads in flight (registers)
+            }
+        };
+        // Z(line) = V(line) R -> workspace; A operand = stored tiles of V (by symmetry)
+        auto gemm_Z = [&](const double (&rop)[NB][2], int pass, int line) __attribute__((always_inline)) {
+          if (SLOD_DG(A, 8))
+            return;
+          const double *vl  = vg + (size_t)line * vline;
+          double       *xl  = xg + (size_t)line * xline;
+          const bool    two = 2 * pass + 1 < nct;
+          double        av[NB], an[NB];
+          auto load_A = [&](int ti, double (&dst)[NB]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int kk = 0; kk < NB; ++kk)
+              dst[kk] = (4 * kk < m) ? (vl + (((kk >> 2) * NT + ti) * 4 + (kk & 3)) * 64)[lane] : 0.0;
+          };
+          load_A(0, av);
+#pragma unroll
+          for (int ti = 0; ti < NT; ++ti)
+            {
+              if (16 * ti >= m) // wave-uniform
+                continue;
+              if (ti + 1 < NT && 16 * (ti + 1) < m)
+                load_A(ti + 1, an);
+              double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+              for (int kk = 0; kk < NB; ++kk)
+                {
+                  if (4 * kk >= m)
+                    continue;
+                  acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], rop[kk][0], acc0, 0, 0, 0);
+                  if (two)
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], rop[kk][1], acc1, 0, 0, 0);
+                }
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                {
+                  const int row = 16 * ti + 4 * r + g, col = 32 * pass + c;
+                  if (row < m && col < nc)
+                    xl[row * ncg + col] = acc0[r];
+                  if (two && row < m && col + 16 < nc)
+                    xl[row * ncg + col + 16] = acc1[r];
+                }
+#pragma unroll
+              for (int kk = 0; kk < NB; ++kk)
+                av[kk] = an[kk];
+            }
+        };
+        double rop[NB][2];
+        auto   rz_line = [&](int t) __attribute__((always_inline)) {
+          // RHS block and Z of line(t-1): its V became visible at A_{t-1}; the coupling
+          // line(t-2) -> line(t-1) is the B band of step t-2
+          const int line = line_of(chain, t - 1);
+          for (int pass = 0; pass < npass; ++pass)
+            {
+              build_rop(rop, pass, line, Bbuf(Bc0, t - 2), t > 1 ? xg + (size_t)line_of(chain, t - 2) * xline : nullptr,
+                        true, false);
+              gemm_Z(rop, pass, line);
+            }
+        };
+        for (int t = 0; t < nstp; ++t)
+          {
+            if (t > 0 && t - 1 < nmy)
+              rz_line(t);
+            if (t > 0 && !SLOD_DG(A, 32))
+              put_step(t + 1, lane, 64); // bands the GJ wave needs after its next sweep
+            __syncthreads(); // A_t
+          }
+        // R/Z of the last step (the shorter chain of an even L already did its last line in the loop)
+        if (nmy == nstp && nmy > 0)
+          rz_line(nstp);
+        __syncthreads(); // M1 (also: both chains' last Z are in the workspace)
+        __syncthreads(); // M2: V_mid is in the workspace
+        if (chain == 0)
+          {
+            // R_mid = F_mid - B^T Z(mid-1) - B'^T Z(mid+1); the bands are the last B of each chain
+            const double *B0 = Bbuf(Bc0, n0 - 1);
+            double       *ob = ocb + 4 * PST + WROWS * WST + 3 * bsz; // other chain's Bc0
+            const double *B1 = Bbuf(ob, n1 - 1);
+            for (int pass = 0; pass < npass; ++pass)
+              {
+                build_rop(rop, pass, mid, B0, n0 > 0 ? xg + (size_t)(mid - 1) * xline : nullptr, true, false);
+                if (n1 > 0)
+                  build_rop(rop, pass, mid, B1, xg + (size_t)(mid + 1) * xline, false, true);
+                gemm_Z(rop, pass, mid); // X_mid
+              }
+          }
+        __syncthreads(); // M3
+      }
+
+    // ------------------------------ backward substitution -------------------------
+    // from the meeting line outwards.  Wave (chain, w) owns the column tiles w, w + 2 of its chain:
+    // X(line) = Z(line) - V(line) (B X(prev)), X(prev) kept in the accumulator layout and, for the
+    // banded product, in a wave-private LDS strip with W zero rows above and below -- no workgroup
+    // barrier, no re-read of X.
+    if (nmy > 0 && !SLOD_DG(A, 16))
+      {
+        constexpr int XROWS = MP + 2 * W;
+        const int     w2    = wave >> 1;
+        double       *xs    = smem + (size_t)wave * (XROWS * XST); // aliases the forward buffers (dead now)
+        for (int x = lane; x < W * XST; x += 64)
+          {
+            xs[x]                    = 0.0;
+            xs[(MP + W) * XST + x] = 0.0;
+          }
+        // scalar problems: the coupling line -> prev of dof i is one stencil plane entry per offset o,
+        // node(i) = nd0 + i * nds (coupling<S>() for vector-valued problems)
+        const int nds = tr ? npx : 1;
+        const int nn  = npx * (d.ny + 1);
+        for (int tj = w2; tj < nct; tj += 2)
+          {
+            const int col  = 16 * tj + c;
+            const bool cok = col < nc;
+            double4_t  xa[NT];
+            {
+              const double *xm = xg + (size_t)mid * xline;
+#pragma unroll
+              for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                  {
+                    const int row = 16 * ti + 4 * r + g;
+                    xa[ti][r]     = (row < m && cok) ? xm[row * ncg + col] : 0.0;
+                  }
+            }
+            for (int t = nmy - 1; t >= 0; --t)
+              {
+                const int     line = line_of(chain, t);
+                const double *vl = vg + (size_t)line * vline;
+                double       *xl = xg + (size_t)line * xline;
+                // X(prev) -> strip
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                  for (int r = 0; r < 4; ++r)
+                    xs[(16 * ti + 4 * r + g + W) * XST + c] = xa[ti][r];
+                // Z(line): start of the accumulators (independent loads, issued early)
+                double4_t xn[NT];
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                  for (int r = 0; r < 4; ++r)
+                    {
+                      const int row = 16 * ti + 4 * r + g;
+                      xn[ti][r]     = (row < m && cok) ? xl[row * ncg + col] : 0.0;
+                    }
+                SLOD_WAVE_SYNC();
+                // B operand: -(B X(prev))[4 kk + g][col], B = coupling line -> prev (stencil planes)
+                const double *bp[BW];
+                const int     nd0 = tr ? (line + 1) + npx : 1 + (line + 1) * npx;
+                if (S == 1)
+                  {
+#pragma unroll
+                    for (int e = 0; e < BW; ++e)
+                      {
+                        const int o = e - W, dx = tr ? dl : o, dy = tr ? o : dl;
+                        bp[e]       = st + (size_t)((dy + 1) * 3 + dx + 1) * A.nn_max;
+                      }
+                  }
+                double yop[NB];
+#pragma unroll
+                for (int kk = 0; kk < NB; ++kk)
+                  {
+                    if (4 * kk >= m)
+                      {
+                        yop[kk] = 0.0;
+                        continue;
+                      }
+                    const int i    = 4 * kk + g;
+                    const int node = min(nd0 + i * nds, nn - 1); // rows >= m: clamped address, dropped below
+                    double    v    = 0.0;
+#pragma unroll
+                    for (int e = 0; e < BW; ++e)
+                      {
+                        double be;
+                        if (S == 1)
+                          be = bp[e][node];
+                        else
+                          be = (i < m) ? coupling<S>(st, A.nn_max, npx, tr, m, line, i, dl, e - W) : 0.0;
+                        // rows outside [0,m) of the strip are zero: no range test on i + e - W
+                        v = fma(-(sc * be), xs[(i + e) * XST + c], v);
+                      }
+                    yop[kk] = (i < m) ? v : 0.0;
+                  }
+                SLOD_WAVE_SYNC(); // the strip is rewritten by the next line
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti)
+                  {
+                    if (16 * ti >= m)
+                      continue;
+#pragma unroll
+                    for (int kk = 0; kk < NB; ++kk)
+                      {
+                        if (4 * kk >= m)
+                          continue;
+                        const double av = (vl + (((kk >> 2) * NT + ti) * 4 + (kk & 3)) * 64)[lane];
+                        xn[ti]          = __builtin_amdgcn_mfma_f64_16x16x4f64(av, yop[kk], xn[ti], 0, 0, 0);
+                      }
+                  }
+#pragma unroll
+                for (int ti = 0; ti < NT; ++ti)
+                  {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                      {
+                        const int row = 16 * ti + 4 * r + g;
+                        if (row < m && cok)
+                          xl[row * ncg + col] = xn[ti][r];
+                      }
+                    xa[ti] = xn[ti];
+                  }
+              }
+          }
+      }
+    // Fused selection stage: the same workgroup goes on with M, D, the boundary trace, the
+    // least squares, phi and psi of its patch.
+    const bool stamp = (SLOD_DG(A, (1 << 20))) && tid == 0 && A.nc_max * A.nc_max >= 12;
+    if (stamp)
+      A.ms[(size_t)blockIdx.x * A.nc_max * A.nc_max + 1] = (double)wall_clock64();
+    if (S == 1 && A.fuse_select)
+      {
+        __syncthreads(); // X of all lines is written; LDS is free
+        select_patch<S>(A, A.nb_buf, A.nf_max, blockIdx.x, smem);
+        if (stamp)
+          A.ms[(size_t)blockIdx.x * A.nc_max * A.nc_max + 2] = (double)wall_clock64();
+      }
+  }
+#undef SLOD_WAVE_SYNC
+
+} // namespace
+
+int slod_solve_mf_tiles(int S, int m_max)
+{
+  const int nt = (m_max + 15) / 16;
+  if (nt < 1 || nt > (S == 1 ? 7 : 5))
+    return 0;
+  return nt;
+}
+
+size_t slod_solve_mf_lds_bytes(int S, int m_max, int nc_max)
+{
+  // must mirror the carve-up at the top of k_solve_mf
+  const int NT = slod_solve_mf_tiles(S, m_max);
+  if (NT == 0)
+    return ~(size_t)0;
+  const int    W = 2 * S - 1, BW = 2 * W + 1, MP = 16 * NT, BWP = BW + 1;
+  const int    bsz = ((MP + 2 * W) * BWP + 1) & ~1, PST = MP + 2, WST = MP + 1, WROWS = 16 + 2 * W;
+  const size_t chsz = (size_t)((4 * PST + WROWS * WST + 6 * bsz + 1) & ~1);
+  size_t       n    = 2 * chsz;
+  const size_t back = (size_t)4 * (MP + 2 * W) * 17; // backward strips alias the chain blocks
+  if (back > n)
+    n = back;
+  return ((n * sizeof(double) + 2 * (size_t)nc_max * sizeof(int)) + 15) & ~(size_t)15;
+}
+
+template <int NT, int S>
+static hipError_t launch_mf_TS(const SlodKernelArgs &a, int n_patches, size_t lds, hipStream_t st)
+{
+  const void *fn = reinterpret_cast<const void *>(k_solve_mf<NT, S>);
+  hipError_t  e  = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess)
+    return e;
+  if (a.debug)
+    {
+      int nb = 0;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, lds);
+      fprintf(stderr, "[slod] k_solve_mf<%d,%d>: %d patches, lds %zu B, occupancy %d blocks/CU\n", NT, S, n_patches,
+              lds, nb);
+    }
+  hipLaunchKernelGGL((k_solve_mf<NT, S>), dim3(n_patches), dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+
+hipError_t slod_launch_solve_mf(int S, const SlodKernelArgs &a, int n_patches, size_t lds, hipStream_t st)
+{
+  const int nt = slod_solve_mf_tiles(S, a.m_max);
+  if (S == 1)
+    switch (nt)
+      {
+        case 1:
+          return launch_mf_TS<1, 1>(a, n_patches, lds, st);
+        case 2:
+          return launch_mf_TS<2, 1>(a, n_patches, lds, st);
+        case 3:
+          return launch_mf_TS<3, 1>(a, n_patches, lds, st);
+        case 4:
+          return launch_mf_TS<4, 1>(a, n_patches, lds, st);
+        case 5:
+          return launch_mf_TS<5, 1>(a, n_patches, lds, st);
+        case 6:
+          return launch_mf_TS<6, 1>(a, n_patches, lds, st);
+        case 7:
+          return launch_mf_TS<7, 1>(a, n_patches, lds, st);
+        default:
+          return hipErrorInvalidValue;
+      }
+  switch (nt)
+    {
+      case 1:
+        return launch_mf_TS<1, 2>(a, n_patches, lds, st);
+      case 2:
+        return launch_mf_TS<2, 2>(a, n_patches, lds, st);
+      case 3:
+        return launch_mf_TS<3, 2>(a, n_patches, lds, st);
+      case 4:
+        return launch_mf_TS<4, 2>(a, n_patches, lds, st);
+      case 5:
+        return launch_mf_TS<5, 2>(a, n_patches, lds, st);
+      default:
+        return hipErrorInvalidValue;
+    }
+}
