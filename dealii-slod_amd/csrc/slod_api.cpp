@@ -51,6 +51,8 @@ struct slod_plan
   size_t                     stride = 0, out_size = 0;
   size_t                     chunk = 0;
   double                    *ws_st = nullptr, *ws_v = nullptr, *ws_x = nullptr, *ws_m = nullptr;
+  double                    *ws_x_alloc = nullptr; // ws_x sits `guard` doubles inside this allocation
+  size_t                     guard = 0;
   size_t                     st_stride = 0, v_stride = 0, x_stride = 0;
   int32_t                   *d_status = nullptr;
   SlodPatchDiag             *d_pdiag  = nullptr; // [n][spacedim] decisions of the selection stage
@@ -550,9 +552,18 @@ int slod_plan_create(slod_handle *h, const uint32_t *gids, size_t n, const uint6
   p->chunk = std::max<size_t>(1, std::min<size_t>(n, budget_mb * 1024 * 1024 / per_patch));
   bool ok  = true;
   ok       = ok && hipMalloc((void **)&p->d_desc, n * sizeof(SlodPatchDesc)) == hipSuccess;
-  ok       = ok && hipMalloc((void **)&p->ws_st, p->chunk * p->st_stride * sizeof(double)) == hipSuccess;
+  // Guards: the kernels read the banded neighbours of a row / node without range tests (the
+  // matching band coefficient is zero, or the result is dropped), so up to a few rows before the
+  // first and after the last slot are touched.  X is zero-filled once: a skipped product must meet
+  // a finite number.
+  p->guard = (size_t)8 * p->nc_max + 64;
+  const size_t st_slack = (size_t)p->nn_max;
+  ok       = ok && hipMalloc((void **)&p->ws_st, (p->chunk * p->st_stride + st_slack) * sizeof(double)) == hipSuccess;
+  ok       = ok && hipMemset(p->ws_st, 0, (p->chunk * p->st_stride + st_slack) * sizeof(double)) == hipSuccess;
   ok       = ok && hipMalloc((void **)&p->ws_v, p->chunk * p->v_stride * sizeof(double)) == hipSuccess;
-  ok       = ok && hipMalloc((void **)&p->ws_x, p->chunk * p->x_stride * sizeof(double)) == hipSuccess;
+  ok       = ok && hipMalloc((void **)&p->ws_x_alloc, (p->chunk * p->x_stride + 2 * p->guard) * sizeof(double)) == hipSuccess;
+  ok       = ok && hipMemset(p->ws_x_alloc, 0, (p->chunk * p->x_stride + 2 * p->guard) * sizeof(double)) == hipSuccess;
+  p->ws_x  = p->ws_x_alloc ? p->ws_x_alloc + p->guard : nullptr;
   ok       = ok && hipMalloc((void **)&p->ws_m, p->chunk * (size_t)p->nc_max * p->nc_max * sizeof(double)) == hipSuccess;
   ok       = ok && hipMalloc((void **)&p->d_status, sizeof(int32_t)) == hipSuccess;
   ok       = ok && hipMalloc((void **)&p->d_pdiag, n * (size_t)s * sizeof(SlodPatchDiag)) == hipSuccess;
@@ -587,8 +598,8 @@ void slod_plan_destroy(slod_plan *p)
     (void)hipFree(p->ws_st);
   if (p->ws_v)
     (void)hipFree(p->ws_v);
-  if (p->ws_x)
-    (void)hipFree(p->ws_x);
+  if (p->ws_x_alloc)
+    (void)hipFree(p->ws_x_alloc);
   if (p->ws_m)
     (void)hipFree(p->ws_m);
   if (p->d_status)

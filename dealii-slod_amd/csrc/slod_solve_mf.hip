@@ -17,9 +17,8 @@ namespace
   //     panel once through a wave-private LDS line: U = -(C[:,K] W), then
   //     C <- C + U * C[K,:] is NT^2 MFMAs, the pivot rows are overwritten by W C[K,:] and -W.
   //     One LDS round trip and ~100 VALU instructions per 4 pivots instead of ~95 per pivot.
-  //   * the next Schur complement T - B^T V B (B banded) stays in registers: the column mixing
-  //     V B uses DPP lane shifts inside the 16-lane rows, the row mixing B^T (V B) a small LDS
-  //     window of one tile row.
+  //   * the next Schur complement T - B^T V B (B banded) is formed in place, one tile row at a
+  //     time, through a small wave-private LDS window: rows (B^T V), then columns ((B^T V) B).
   //   * right-hand sides are independent per column: a helper wave (forward) / every wave
   //     (backward) owns 16-column tiles of Z/X, keeps them in the accumulator layout -- which is
   //     the B operand layout of the next product -- and needs no workgroup barrier in the
@@ -32,34 +31,6 @@ namespace
   __host__ __device__ constexpr int mf_min_waves(int NT, int S) { return NT <= 4 ? 2 : 1; }
 
   typedef double double2_t __attribute__((ext_vector_type(2)));
-
-  // lanes whose DPP source is inside the row take it, the others keep `old`
-  template <int CTRL>
-  __device__ __forceinline__ double dpp_upd(double old, double v)
-  {
-    union
-    {
-      double d;
-      int    i[2];
-    } o, in, out;
-    o.d      = old;
-    in.d     = v;
-    out.i[0] = __builtin_amdgcn_update_dpp(o.i[0], in.i[0], CTRL, 0xf, 0xf, false);
-    out.i[1] = __builtin_amdgcn_update_dpp(o.i[1], in.i[1], CTRL, 0xf, 0xf, false);
-    return out.d;
-  }
-  // value of column j - w / j + w of a tile row: inside the tile from lane c -+ w (row_shr / row_shl),
-  // across the tile edge from the neighbouring tile's register (row_ror)
-  template <int w>
-  __device__ __forceinline__ double col_left(double cur, double prev_tile)
-  {
-    return dpp_upd<0x110 + w>(dpp_rot<0x120 + w>(prev_tile), cur);
-  }
-  template <int w>
-  __device__ __forceinline__ double col_right(double cur, double next_tile)
-  {
-    return dpp_upd<0x100 + w>(dpp_rot<0x120 + 16 - w>(next_tile), cur);
-  }
 
 #define SLOD_WAVE_SYNC()                                        \
   do                                                            \
@@ -78,10 +49,13 @@ namespace
     constexpr int       W = 2 * S - 1, BW = 2 * W + 1, MP = 16 * NT, NB = MP / 4;
     constexpr int       BWP = BW + 1, BROWS = MP + 2 * W, bsz = (BROWS * BWP + 1) & ~1;
     constexpr int       PST = MP + 2;          // panel row stride (even: 16-byte aligned pivot block)
-    constexpr int       WST = MP + 1, WROWS = 16 + 2 * W; // row-mixing window
+    constexpr int       WST = MP + 2 * W + 1, WROWS = 16 + 3 * W; // mixing window (+ W saved halo rows)
     constexpr int       XST = 17;              // backward strips: [MP + 2 W][16 + 1]
     constexpr int       chsz = (4 * PST + WROWS * WST + 6 * bsz + 1) & ~1; // doubles per chain
-    const int           tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int           tid = threadIdx.x, lane = tid & 63;
+    // the wave index is uniform: as a scalar the role branches are scalar branches and every
+    // per-chain LDS / workspace base stays in SGPRs
+    const int           wave  = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int           chain = wave & 1;
     const bool          is_gj = wave < 2;
     const int           g = lane >> 4, c = lane & 15;
@@ -93,7 +67,8 @@ namespace
 
     double *cb    = smem + chain * chsz;
     double *panel = cb;                  // [4][PST]      pivot rows of the current block step
-    double *ywin  = panel + 4 * PST;     // [WROWS][WST]  one tile row of V B (+ halo rows)
+    double *ywin  = panel + 4 * PST;     // [16 + 2 W][WST]  one tile row of V (+ halo rows / zero halo columns)
+    double *yhs   = ywin + (16 + 2 * W) * WST; // [W][WST]    saved halo rows for the next tile row
     double *Tf    = ywin + WROWS * WST;  // padded bands: T of the chain's first line,
     double *Tn0   = Tf + bsz;            //   T bands of the steps (by step parity),
     double *Tn1   = Tn0 + bsz;
@@ -187,53 +162,59 @@ namespace
     __syncthreads();
 
     // ------------------------------ forward elimination ---------------------------
+    // Per-lane constants (tile coordinates, LDS addresses, masks) are re-derived from an opaque
+    // copy of the lane id wherever they are used: written once up front, the compiler hoists every
+    // address and mask of the unrolled code out of the line loops and spills them, and a reload
+    // from scratch sits on the dependent chain.  Redoing them costs one or two VALU each.
+    auto olane = [&]() __attribute__((always_inline)) {
+      int l = lane;
+      asm volatile("" : "+v"(l));
+      return l;
+    };
     if (is_gj)
       {
         __builtin_amdgcn_s_setprio(3);
-        double4_t    acc[NT][NT];
-        const int    c3  = c & 3;
-        const double dlt = (g == c3) ? 1.0 : 0.0;
-        double       eg[4];
+        double4_t acc[NT][NT];
+        bool      bad = false;
+
+        // entry (16 ti + 4 r + g, 16 tj + c) of a padded T band buffer, |ti - tj| <= 1: element
+        // 16 ti BWP + toff[tj - ti + 1][r] (column BW of a band row is a zero pad); identity on
+        // the padding diagonal
+        auto t_offsets = [&](int og, int oc, int (&toff)[3][4]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          eg[k] = (g == k) ? 1.0 : 0.0;
-        bool bad = false;
-        // entry (16 ti + 4 r + g, 16 tj + c) of a padded T band buffer, |ti - tj| <= 1: offset
-        // 16 ti BWP + toff[tj - ti + 1][r]; column BW of a band row is a zero pad
-        int  toff[3][4];
-        bool isd[4];
+          for (int r = 0; r < 4; ++r)
+            {
+              const int rho = 4 * r + og;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          {
-            const int rho = 4 * r + g;
-#pragma unroll
-            for (int dt = 0; dt < 3; ++dt)
-              {
-                const unsigned oi = (unsigned)(c + 16 * (dt - 1) - rho + W);
-                toff[dt][r]       = (rho + W) * BWP + (int)(oi < (unsigned)BW ? oi : (unsigned)BW);
-              }
-            isd[r] = rho == c;
-          }
-        auto t_entry = [&](const double *Tsrc, int ti, int tj, int r, bool pad_identity) __attribute__((always_inline)) {
+              for (int dt = 0; dt < 3; ++dt)
+                {
+                  const unsigned oi = (unsigned)(oc + 16 * (dt - 1) - rho + W);
+                  toff[dt][r]       = (rho + W) * BWP + (int)(oi < (unsigned)BW ? oi : (unsigned)BW);
+                }
+            }
+        };
+        auto t_entry = [&](const double *Tsrc, const int (&toff)[3][4], int og, int oc, int ti, int tj, int r,
+                           bool pad_identity) __attribute__((always_inline)) {
           double v = 0.0;
           if (tj - ti <= 1 && ti - tj <= 1)
             {
               v = Tsrc[16 * ti * BWP + toff[tj - ti + 1][r]];
               if (ti == tj && pad_identity)
-                v = (isd[r] && 16 * ti + c >= m) ? 1.0 : v; // identity on the padding diagonal
+                v = (4 * r + og == oc && 16 * ti + oc >= m) ? 1.0 : v;
             }
           return v;
         };
-
-        // acc <- bands of T (zero outside the band), identity on the padding diagonal
         auto t_init = [&](const double *Tsrc, bool pad_identity) __attribute__((always_inline)) {
+          const int ol = olane(), og = ol >> 4, oc = ol & 15;
+          int       toff[3][4];
+          t_offsets(og, oc, toff);
 #pragma unroll
           for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
             for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
               for (int r = 0; r < 4; ++r)
-                acc[ti][tj][r] = t_entry(Tsrc, ti, tj, r, pad_identity);
+                acc[ti][tj][r] = t_entry(Tsrc, toff, og, oc, ti, tj, r, pad_identity);
         };
 
         // blocked symmetric sweep of all pivots < m: acc <- -S^-1 (padding: -1 / identity, decoupled)
@@ -244,14 +225,16 @@ namespace
               if (4 * kb >= m || (SLOD_DG(A, 4) && kb > 0)) // wave-uniform
                 continue;
               const int  tk = kb >> 2, q = kb & 3;
-              const bool inK = (c >> 2) == q;
+              const int  ol = olane(), og = ol >> 4, oc = ol & 15, oc3 = ol & 3;
+              const bool inK = (oc >> 2) == q;
               // pivot rows -> panel (they are the B operand C[K,:] already)
-              double vt[NT];
+              double  vt[NT];
+              double *pwr = panel + og * PST + oc;
 #pragma unroll
               for (int tj = 0; tj < NT; ++tj)
                 {
-                  vt[tj]                          = acc[tk][tj][q];
-                  panel[g * PST + 16 * tj + c] = vt[tj];
+                  vt[tj]       = acc[tk][tj][q];
+                  pwr[16 * tj] = vt[tj];
                 }
               SLOD_WAVE_SYNC();
               // pivot block (uniform addresses), upper triangle
@@ -263,13 +246,6 @@ namespace
               const double     a00 = r00.x, a01 = r00.y, a02 = r01.x, a03 = r01.y;
               const double     a11 = r10.y, a12 = r11.x, a13 = r11.y;
               const double     a22 = r21.x, a23 = r21.y, a33 = r31.y;
-              // panel columns of this lane: C[K_k][16 ti + c]
-              double pc[NT][4];
-#pragma unroll
-              for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                  pc[ti][k] = panel[k * PST + 16 * ti + c];
               // C_KK = L D L^T, then row g of W = C_KK^-1: solve C_KK w = e_g
               bad |= !(a00 > 0.0);
               const double p0  = fast_rcp(a00);
@@ -287,115 +263,125 @@ namespace
               bad |= !(d33 > 0.0);
               const double p3 = fast_rcp(d33);
               // forward (L y = e_g), scale (D), backward (L^T w = z)
-              const double y0 = eg[0];
-              const double y1 = fma(-l10, y0, eg[1]);
-              const double y2 = fma(-l21, y1, fma(-l20, y0, eg[2]));
-              const double y3 = fma(-l32, y2, fma(-l31, y1, fma(-l30, y0, eg[3])));
+              const double e0 = og == 0 ? 1.0 : 0.0, e1 = og == 1 ? 1.0 : 0.0, e2 = og == 2 ? 1.0 : 0.0,
+                           e3 = og == 3 ? 1.0 : 0.0;
+              const double y0 = e0;
+              const double y1 = fma(-l10, y0, e1);
+              const double y2 = fma(-l21, y1, fma(-l20, y0, e2));
+              const double y3 = fma(-l32, y2, fma(-l31, y1, fma(-l30, y0, e3)));
               const double w3 = y3 * p3;
               const double w2 = fma(-l32, w3, y2 * p2);
               const double w1 = fma(-l31, w3, fma(-l21, w2, y1 * p1));
               const double w0 = fma(-l30, w3, fma(-l20, w2, fma(-l10, w1, y0 * p0)));
-              // A operand U = -(C[:,K] W): lane (g,c) holds U[16 ti + c][g]
-              double u[NT];
+              // A operand U = -(C[:,K] W): lane (g,c) holds U[16 ti + c][g]; panel column of this lane
+              double        u[NT];
+              const double *prd = panel + oc;
 #pragma unroll
               for (int ti = 0; ti < NT; ++ti)
-                u[ti] = -fma(w3, pc[ti][3], fma(w2, pc[ti][2], fma(w1, pc[ti][1], w0 * pc[ti][0])));
+                u[ti] = -fma(w3, prd[3 * PST + 16 * ti],
+                             fma(w2, prd[2 * PST + 16 * ti], fma(w1, prd[PST + 16 * ti], w0 * prd[16 * ti])));
               // B operand: C[K,:], with C_KK - I in the pivot columns (so that C[J,K] <- C[J,K] W)
-              vt[tk] -= inK ? dlt : 0.0;
+              vt[tk] -= (inK && og == oc3) ? 1.0 : 0.0;
 #pragma unroll
               for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
                 for (int tj = 0; tj < NT; ++tj)
                   acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[ti], vt[tj], acc[ti][tj], 0, 0, 0);
               // pivot rows: W C[K,:] = -U, and -W in the pivot block
-              const double wsel = c3 == 0 ? w0 : (c3 == 1 ? w1 : (c3 == 2 ? w2 : w3));
+              const double wsel = oc3 == 0 ? w0 : (oc3 == 1 ? w1 : (oc3 == 2 ? w2 : w3));
 #pragma unroll
               for (int tj = 0; tj < NT; ++tj)
                 acc[tk][tj][q] = (tj == tk && inK) ? -wsel : -u[tj];
             }
         };
 
-        // acc = -V_l  ->  acc = T_next - B^T V_l B = T_next + B^T acc B   (B = coupling l -> l+1)
+        // acc = -V_l  ->  acc = T_next - B^T V_l B = T_next + B^T acc B   (B = coupling l -> l+1).
+        // Both banded products go through a small LDS window, one tile row at a time and in place:
+        // rows first (Y = B^T acc needs the W rows above and below: halo rows of the window), then
+        // columns (Y B needs the W columns left and right: the window has zero halo columns).
         auto next_S = [&](const double *Tsrc, const double *Bl, bool pad_identity) __attribute__((always_inline)) {
-          // stage A, column mixing in registers: Y[i][j] = sum_e acc[i][j + e - W] * B[j + e - W][j]
 #pragma unroll
           for (int ti = 0; ti < NT; ++ti)
             {
-              double4_t y[NT];
-#pragma unroll
-              for (int tj = 0; tj < NT; ++tj)
-                {
-                  double cbv[BW];
-#pragma unroll
-                  for (int e = 0; e < BW; ++e)
-                    cbv[e] = Bl[(16 * tj + c + e) * BWP + (2 * W - e)];
-#pragma unroll
-                  for (int r = 0; r < 4; ++r)
-                    {
-                      const double cur = acc[ti][tj][r];
-                      const double pv  = tj > 0 ? acc[ti][tj > 0 ? tj - 1 : 0][r] : 0.0;
-                      const double nx  = tj + 1 < NT ? acc[ti][tj + 1 < NT ? tj + 1 : tj][r] : 0.0;
-                      double       v   = cbv[W] * cur;
-                      v                = fma(cbv[W - 1], col_left<1>(cur, pv), v);
-                      v                = fma(cbv[W + 1], col_right<1>(cur, nx), v);
-                      if (W > 1)
-                        {
-                          v = fma(cbv[W > 1 ? W - 2 : 0], col_left<(W > 1 ? 2 : 1)>(cur, pv), v);
-                          v = fma(cbv[W > 1 ? W + 2 : 0], col_right<(W > 1 ? 2 : 1)>(cur, nx), v);
-                          v = fma(cbv[W > 1 ? W - 3 : 0], col_left<(W > 1 ? 3 : 1)>(cur, pv), v);
-                          v = fma(cbv[W > 1 ? W + 3 : 0], col_right<(W > 1 ? 3 : 1)>(cur, nx), v);
-                        }
-                      y[tj][r] = v;
-                    }
-                }
-#pragma unroll
-              for (int tj = 0; tj < NT; ++tj)
-                acc[ti][tj] = y[tj];
-              __builtin_amdgcn_sched_barrier(0);
-            }
-          // stage B, row mixing through the LDS window, one tile row at a time:
-          // acc[i][j] = T[i][j] + sum_e B[i + e - W][i] * Y[i + e - W][j]
-#pragma unroll
-          for (int ti = 0; ti < NT; ++ti)
-            {
-              // upper halo: the last W rows of the previous tile row (still in the window)
-              for (int x = lane; x < W * WST; x += 64)
-                ywin[x] = ti > 0 ? ywin[16 * WST + x] : 0.0;
+              const int ol = olane(), og = ol >> 4, oc = ol & 15;
+              int       toff[3][4];
+              t_offsets(og, oc, toff);
+              // ---- rows.  upper halo: the un-mixed last W rows of the previous tile row (saved in yhs)
+              for (int x = ol; x < W * WST; x += 64)
+                ywin[x] = ti > 0 ? yhs[x] : 0.0;
+              double *yw = ywin + (og + W) * WST + oc + W; // own row 4 r + g, column c of a tile
 #pragma unroll
               for (int tj = 0; tj < NT; ++tj)
                 {
 #pragma unroll
                   for (int r = 0; r < 4; ++r)
-                    ywin[(4 * r + g + W) * WST + 16 * tj + c] = acc[ti][tj][r];
-                  if (g < W) // lower halo: the first W rows of the next tile row
-                    ywin[(16 + W + g) * WST + 16 * tj + c] = ti + 1 < NT ? acc[ti + 1 < NT ? ti + 1 : ti][tj][0] : 0.0;
+                    yw[4 * r * WST + 16 * tj] = acc[ti][tj][r];
+                  if (og < W) // lower halo: the first W rows of the next tile row
+                    yw[16 * WST + 16 * tj] = ti + 1 < NT ? acc[ti + 1 < NT ? ti + 1 : ti][tj][0] : 0.0;
                 }
               SLOD_WAVE_SYNC();
+              if (ti + 1 < NT)
+                for (int x = ol; x < W * WST; x += 64)
+                  yhs[x] = ywin[16 * WST + x];
+              {
+                const double *rbp = Bl + og * BWP + 2 * W;       // B[i + e - W][i] = rbp[(16 ti + 4 r + e) BWP - e]
+                const double *yr  = ywin + og * WST + oc + W;     // acc[i + e - W][j] = yr[(4 r + e) WST + 16 tj]
 #pragma unroll
-              for (int r = 0; r < 4; ++r)
-                {
-                  const int i = 16 * ti + 4 * r + g;
-                  double    rb[BW];
+                for (int r = 0; r < 4; ++r)
+                  {
+                    double rb[BW];
 #pragma unroll
-                  for (int e = 0; e < BW; ++e)
-                    rb[e] = Bl[(i + e) * BWP + (2 * W - e)];
+                    for (int e = 0; e < BW; ++e)
+                      rb[e] = rbp[(16 * ti + 4 * r + e) * BWP - e];
 #pragma unroll
-                  for (int tj = 0; tj < NT; ++tj)
-                    {
-                      const int j = 16 * tj + c;
-                      double    v = t_entry(Tsrc, ti, tj, r, pad_identity);
+                    for (int tj = 0; tj < NT; ++tj)
+                      {
+                        double v = rb[W] * acc[ti][tj][r];
 #pragma unroll
-                      for (int e = 0; e < BW; ++e)
-                        v = fma(rb[e], e == W ? acc[ti][tj][r] : ywin[(4 * r + g + e) * WST + j], v);
-                      acc[ti][tj][r] = v;
-                    }
-                }
+                        for (int e = 0; e < BW; ++e)
+                          if (e != W)
+                            v = fma(rb[e], yr[(4 * r + e) * WST + 16 * tj], v);
+                        acc[ti][tj][r] = v;
+                      }
+                  }
+              }
+              SLOD_WAVE_SYNC(); // every read of the un-mixed rows precedes the rewrite
+              // ---- columns: acc[i][j] = T[i][j] + sum_f Y[i][j + f - W] B[j + f - W][j]
+#pragma unroll
+              for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                  yw[4 * r * WST + 16 * tj] = acc[ti][tj][r];
+              SLOD_WAVE_SYNC();
+              {
+                const double *cbp = Bl + oc * BWP + 2 * W;          // B[j + f - W][j] = cbp[(16 tj + f) BWP - f]
+                const double *yc  = ywin + (og + W) * WST + oc;      // Y[i][j + f - W] = yc[4 r WST + 16 tj + f]
+#pragma unroll
+                for (int tj = 0; tj < NT; ++tj)
+                  {
+                    double cbv[BW];
+#pragma unroll
+                    for (int f = 0; f < BW; ++f)
+                      cbv[f] = cbp[(16 * tj + f) * BWP - f];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                      {
+                        double v = fma(cbv[W], acc[ti][tj][r], t_entry(Tsrc, toff, og, oc, ti, tj, r, pad_identity));
+#pragma unroll
+                        for (int f = 0; f < BW; ++f)
+                          if (f != W)
+                            v = fma(cbv[f], yc[4 * r * WST + 16 * tj + f], v);
+                        acc[ti][tj][r] = v;
+                      }
+                  }
+              }
               SLOD_WAVE_SYNC();
             }
         };
 
         // tiles <-> workspace (accumulator layout: 512-byte coalesced per register)
         auto store_tiles = [&](double *dst, double sign) __attribute__((always_inline)) {
+          const unsigned ul = (unsigned)olane();
 #pragma unroll
           for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
@@ -403,7 +389,7 @@ namespace
               {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                  (dst + ((ti * NT + tj) * 4 + r) * 64)[lane] = sign * acc[ti][tj][r]; // uniform base + lane
+                  (dst + ((ti * NT + tj) * 4 + r) * 64)[ul] = sign * acc[ti][tj][r]; // uniform base + lane
                 __builtin_amdgcn_sched_barrier(0); // one tile at a time: no 36 negated copies in flight
               }
         };
@@ -438,7 +424,8 @@ namespace
         __syncthreads(); // M1: chain 1's contribution is in the workspace
         if (chain == 0)
           {
-            const double *w1 = vg + (size_t)mid * vline;
+            const double  *w1 = vg + (size_t)mid * vline;
+            const unsigned ul = (unsigned)olane();
 #pragma unroll
             for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
@@ -446,7 +433,7 @@ namespace
                 {
 #pragma unroll
                   for (int r = 0; r < 4; ++r)
-                    acc[ti][tj][r] += (w1 + ((ti * NT + tj) * 4 + r) * 64)[lane];
+                    acc[ti][tj][r] += (w1 + ((ti * NT + tj) * 4 + r) * 64)[ul];
                   __builtin_amdgcn_sched_barrier(0);
                 }
             sweep();
@@ -461,27 +448,47 @@ namespace
     else
       {
         // ===== helper wave of the chain: right-hand sides of the line one step behind =====
-        // B operand of Z = V R for a pair of column tiles: rop[kk][t2] = R[4 kk + g][16 (2 pass + t2) + c],
-        // R = (with_F ? F_line : 0) - Bprev^T Z(prev line) [+ rop]; Z from the workspace
-        // weight of P^T along one coordinate: node offset j inside the cell (0 .. n), else 0
-        auto pw1 = [&](int j) { return (unsigned)j > (unsigned)n ? 0.0 : ((j == 0 || j == n) ? 1.0 : 2.0); };
+        // Column tile pair `pass` = columns 32 pass .. 32 pass + 31.  Per pass and half (t2), line
+        // invariant: cell origin across the lines (kL) and the along-the-line weight pattern of
+        // P^T as 2-bit codes per k-step (0, 1, 2 = the weights themselves).
+        int      kL[2][2];
+        unsigned long long wcode[2][2];
+        {
+          const int g0 = lane >> 4, c0 = lane & 15;
+#pragma unroll
+          for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2)
+              {
+                const int cc  = min(32 * pass + 16 * t2 + c0, nc - 1);
+                const int kxn = colk[cc] * n, kyn = colk[A.nc_max + cc] * n;
+                kL[pass][t2]  = tr ? kxn : kyn;
+                const int kA  = tr ? kyn : kxn;
+                unsigned long long code = 0;
+                if (S == 1)
+                  for (int kk = 0; kk < NB; ++kk)
+                    {
+                      const int j = 4 * kk + g0 + 1 - kA;
+                      code |= (unsigned long long)((unsigned)j > (unsigned)n ? 0u : ((j == 0 || j == n) ? 1u : 2u)) << (2 * kk);
+                    }
+                wcode[pass][t2] = code;
+              }
+        }
+        // B operand of Z = V R: rop[kk][t2] = R[4 kk + g][32 pass + 16 t2 + c],
+        // R = (with_F ? F_line : 0) - Bprev^T Z(prev line) [+ rop]; Z from the workspace, no range
+        // tests: outside [0,m) the band coefficient is zero and the workspace is guarded
         auto build_rop = [&](double (&rop)[NB][2], int pass, int line, const double *Bprev, const double *zprev,
                              bool with_F, bool add) __attribute__((always_inline)) {
-          int           kA[2], col[2];
-          bool          cok[2];
-          double        wL[2];
-          const double *zc[2];
+          const int      ol = olane(), og = ol >> 4, oc = ol & 15;
+          const unsigned zl = (unsigned)(og * ncg + oc);              // lane part of a workspace address
+          const double  *bcp = Bprev + og * BWP + 2 * W;              // B[i + e - W][i] = bcp[(4 kk + e) BWP - e]
+          const double  *zb  = zprev ? zprev - W * ncg + 32 * pass : nullptr;
+          double         wL[2];
 #pragma unroll
           for (int t2 = 0; t2 < 2; ++t2)
             {
-              col[t2]       = 16 * (2 * pass + t2) + c;
-              cok[t2]       = col[t2] < nc;
-              const int cc  = min(col[t2], nc - 1);
-              const int kxn = colk[cc] * n, kyn = colk[A.nc_max + cc] * n;
-              // scalar problems: F = scale * w(along the line) * w(across); the across factor per line
-              kA[t2] = tr ? kyn : kxn;
-              wL[t2] = scF * pw1(line + 1 - (tr ? kxn : kyn));
-              zc[t2] = zprev ? zprev + cc : nullptr; // clamped column: the result is dropped below
+              const int j = line + 1 - kL[pass][t2];
+              wL[t2]      = (unsigned)j > (unsigned)n ? 0.0 : ((j == 0 || j == n) ? scF : 2.0 * scF);
             }
 #pragma unroll
           for (int kk = 0; kk < NB; ++kk)
@@ -491,38 +498,33 @@ namespace
                   rop[kk][0] = rop[kk][1] = 0.0;
                   continue;
                 }
-              const int i = 4 * kk + g;
-              double    bc[BW];
-              int       pe[BW];
+              double bc[BW];
 #pragma unroll
               for (int e = 0; e < BW; ++e)
-                {
-                  bc[e] = Bprev[(i + e) * BWP + (2 * W - e)]; // B[p][i], p = i + e - W; zero band rows outside [0,m)
-                  pe[e] = min(max(i + e - W, 0), m - 1) * ncg;  // clamped row: its coefficient is zero
-                }
+                bc[e] = bcp[(4 * kk + e) * BWP - e];
 #pragma unroll
               for (int t2 = 0; t2 < 2; ++t2)
                 {
-                  const bool ok = cok[t2] && i < m;
-                  double     v  = add ? rop[kk][t2] : 0.0;
+                  double v = add ? rop[kk][t2] : 0.0;
                   if (with_F)
                     {
                       if (S == 1)
-                        v = fma(wL[t2], pw1(i + 1 - kA[t2]), v);
+                        v = fma(wL[t2], (double)(unsigned)((wcode[pass][t2] >> (2 * kk)) & 3u), v);
                       else
                         {
-                          const int pos = i / S, comp = i - pos * S;
+                          const int i = 4 * kk + og, pos = i / S, comp = i - pos * S;
                           const int ix = tr ? line + 1 : pos + 1, iy = tr ? pos + 1 : line + 1;
-                          v += scF * pt_weight<S>(d, n, A.quirk, ix, iy, comp, min(col[t2], nc - 1));
+                          v += scF * pt_weight<S>(d, n, A.quirk, ix, iy, comp, min(32 * pass + 16 * t2 + oc, nc - 1));
                         }
                     }
                   if (zprev)
                     {
 #pragma unroll
                       for (int e = 0; e < BW; ++e)
-                        v = fma(-bc[e], zc[t2][pe[e]], v);
+                        v = fma(-bc[e], (zb + (4 * kk + e) * ncg + 16 * t2)[zl], v);
                     }
-                  rop[kk][t2] = ok ? v : 0.0;
+                  const bool ok = 4 * kk + og < m && 32 * pass + 16 * t2 + oc < nc;
+                  rop[kk][t2]   = ok ? v : 0.0;
                 }
               if (kk % 3 == 2)
                 __builtin_amdgcn_sched_barrier(0); // bounds the loads in flight (registers)
@@ -532,14 +534,16 @@ namespace
         auto gemm_Z = [&](const double (&rop)[NB][2], int pass, int line) __attribute__((always_inline)) {
           if (SLOD_DG(A, 8))
             return;
-          const double *vl  = vg + (size_t)line * vline;
-          double       *xl  = xg + (size_t)line * xline;
-          const bool    two = 2 * pass + 1 < nct;
-          double        av[NB], an[NB];
+          const double  *vl  = vg + (size_t)line * vline;
+          double        *xl  = xg + (size_t)line * xline + 32 * pass;
+          const bool     two = 2 * pass + 1 < nct;
+          const int      ol = olane(), og = ol >> 4, oc = ol & 15;
+          const unsigned ul = (unsigned)ol, zl = (unsigned)(og * ncg + oc);
+          double         av[NB], an[NB];
           auto load_A = [&](int ti, double (&dst)[NB]) __attribute__((always_inline)) {
 #pragma unroll
             for (int kk = 0; kk < NB; ++kk)
-              dst[kk] = (4 * kk < m) ? (vl + (((kk >> 2) * NT + ti) * 4 + (kk & 3)) * 64)[lane] : 0.0;
+              dst[kk] = (4 * kk < m) ? (vl + (((kk >> 2) * NT + ti) * 4 + (kk & 3)) * 64)[ul] : 0.0;
           };
           load_A(0, av);
 #pragma unroll
@@ -562,11 +566,12 @@ namespace
 #pragma unroll
               for (int r = 0; r < 4; ++r)
                 {
-                  const int row = 16 * ti + 4 * r + g, col = 32 * pass + c;
+                  const int  row = 16 * ti + 4 * r + og, col = 32 * pass + oc;
+                  double    *xr  = xl + (16 * ti + 4 * r) * ncg;
                   if (row < m && col < nc)
-                    xl[row * ncg + col] = acc0[r];
+                    xr[zl] = acc0[r];
                   if (two && row < m && col + 16 < nc)
-                    xl[row * ncg + col + 16] = acc1[r];
+                    (xr + 16)[zl] = acc1[r];
                 }
 #pragma unroll
               for (int kk = 0; kk < NB; ++kk)
@@ -578,12 +583,14 @@ namespace
           // RHS block and Z of line(t-1): its V became visible at A_{t-1}; the coupling
           // line(t-2) -> line(t-1) is the B band of step t-2
           const int line = line_of(chain, t - 1);
-          for (int pass = 0; pass < npass; ++pass)
-            {
-              build_rop(rop, pass, line, Bbuf(Bc0, t - 2), t > 1 ? xg + (size_t)line_of(chain, t - 2) * xline : nullptr,
-                        true, false);
-              gemm_Z(rop, pass, line);
-            }
+#pragma unroll
+          for (int pass = 0; pass < 2; ++pass)
+            if (pass < npass)
+              {
+                build_rop(rop, pass, line, Bbuf(Bc0, t - 2),
+                          t > 1 ? xg + (size_t)line_of(chain, t - 2) * xline : nullptr, true, false);
+                gemm_Z(rop, pass, line);
+              }
         };
         for (int t = 0; t < nstp; ++t)
           {
@@ -604,13 +611,15 @@ namespace
             const double *B0 = Bbuf(Bc0, n0 - 1);
             double       *ob = ocb + 4 * PST + WROWS * WST + 3 * bsz; // other chain's Bc0
             const double *B1 = Bbuf(ob, n1 - 1);
-            for (int pass = 0; pass < npass; ++pass)
-              {
-                build_rop(rop, pass, mid, B0, n0 > 0 ? xg + (size_t)(mid - 1) * xline : nullptr, true, false);
-                if (n1 > 0)
-                  build_rop(rop, pass, mid, B1, xg + (size_t)(mid + 1) * xline, false, true);
-                gemm_Z(rop, pass, mid); // X_mid
-              }
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass)
+              if (pass < npass)
+                {
+                  build_rop(rop, pass, mid, B0, n0 > 0 ? xg + (size_t)(mid - 1) * xline : nullptr, true, false);
+                  if (n1 > 0)
+                    build_rop(rop, pass, mid, B1, xg + (size_t)(mid + 1) * xline, false, true);
+                  gemm_Z(rop, pass, mid); // X_mid
+                }
           }
         __syncthreads(); // M3
       }
@@ -619,7 +628,7 @@ namespace
     // from the meeting line outwards.  Wave (chain, w) owns the column tiles w, w + 2 of its chain:
     // X(line) = Z(line) - V(line) (B X(prev)), X(prev) kept in the accumulator layout and, for the
     // banded product, in a wave-private LDS strip with W zero rows above and below -- no workgroup
-    // barrier, no re-read of X.
+    // barrier, no re-read of X.  V tiles are fetched one tile row ahead (across lines too).
     if (nmy > 0 && !SLOD_DG(A, 16))
       {
         constexpr int XROWS = MP + 2 * W;
@@ -633,34 +642,42 @@ namespace
         // scalar problems: the coupling line -> prev of dof i is one stencil plane entry per offset o,
         // node(i) = nd0 + i * nds (coupling<S>() for vector-valued problems)
         const int nds = tr ? npx : 1;
-        const int nn  = npx * (d.ny + 1);
         for (int tj = w2; tj < nct; tj += 2)
           {
-            const int col  = 16 * tj + c;
-            const bool cok = col < nc;
-            double4_t  xa[NT];
+            const int      ol = olane(), og = ol >> 4, oc = ol & 15;
+            const unsigned ul = (unsigned)ol, zl = (unsigned)(og * ncg + oc), sl = (unsigned)(og * nds);
+            const bool     cok = 16 * tj + oc < nc;
+            double        *xsl = xs + og * XST + oc; // strip row 4 r + g - W ... of this lane
+            double4_t      xa[NT];
             {
-              const double *xm = xg + (size_t)mid * xline;
+              const double *xm = xg + (size_t)mid * xline + 16 * tj;
 #pragma unroll
               for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                   {
-                    const int row = 16 * ti + 4 * r + g;
-                    xa[ti][r]     = (row < m && cok) ? xm[row * ncg + col] : 0.0;
+                    const double v = (xm + (16 * ti + 4 * r) * ncg)[zl];
+                    xa[ti][r]      = (16 * ti + 4 * r + og < m && cok) ? v : 0.0;
                   }
             }
+            double av[NB], an[NB];
+            auto   load_V = [&](const double *vl, int ti, double (&dst)[NB]) __attribute__((always_inline)) {
+#pragma unroll
+              for (int kk = 0; kk < NB; ++kk)
+                dst[kk] = (4 * kk < m) ? (vl + (((kk >> 2) * NT + ti) * 4 + (kk & 3)) * 64)[ul] : 0.0;
+            };
+            load_V(vg + (size_t)line_of(chain, nmy - 1) * vline, 0, av);
             for (int t = nmy - 1; t >= 0; --t)
               {
                 const int     line = line_of(chain, t);
                 const double *vl = vg + (size_t)line * vline;
-                double       *xl = xg + (size_t)line * xline;
+                double       *xl = xg + (size_t)line * xline + 16 * tj;
                 // X(prev) -> strip
 #pragma unroll
                 for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
                   for (int r = 0; r < 4; ++r)
-                    xs[(16 * ti + 4 * r + g + W) * XST + c] = xa[ti][r];
+                    xsl[(16 * ti + 4 * r + W) * XST] = xa[ti][r];
                 // Z(line): start of the accumulators (independent loads, issued early)
                 double4_t xn[NT];
 #pragma unroll
@@ -668,21 +685,18 @@ namespace
 #pragma unroll
                   for (int r = 0; r < 4; ++r)
                     {
-                      const int row = 16 * ti + 4 * r + g;
-                      xn[ti][r]     = (row < m && cok) ? xl[row * ncg + col] : 0.0;
+                      const double v = (xl + (16 * ti + 4 * r) * ncg)[zl];
+                      xn[ti][r]      = (16 * ti + 4 * r + og < m && cok) ? v : 0.0;
                     }
                 SLOD_WAVE_SYNC();
                 // B operand: -(B X(prev))[4 kk + g][col], B = coupling line -> prev (stencil planes)
                 const double *bp[BW];
                 const int     nd0 = tr ? (line + 1) + npx : 1 + (line + 1) * npx;
-                if (S == 1)
-                  {
 #pragma unroll
-                    for (int e = 0; e < BW; ++e)
-                      {
-                        const int o = e - W, dx = tr ? dl : o, dy = tr ? o : dl;
-                        bp[e]       = st + (size_t)((dy + 1) * 3 + dx + 1) * A.nn_max;
-                      }
+                for (int e = 0; e < BW; ++e)
+                  {
+                    const int o = e - W, dx = tr ? dl : o, dy = tr ? o : dl;
+                    bp[e]       = st + (size_t)((dy + 1) * 3 + dx + 1) * A.nn_max + nd0;
                   }
                 double yop[NB];
 #pragma unroll
@@ -693,21 +707,19 @@ namespace
                         yop[kk] = 0.0;
                         continue;
                       }
-                    const int i    = 4 * kk + g;
-                    const int node = min(nd0 + i * nds, nn - 1); // rows >= m: clamped address, dropped below
-                    double    v    = 0.0;
+                    double v = 0.0;
 #pragma unroll
                     for (int e = 0; e < BW; ++e)
                       {
                         double be;
-                        if (S == 1)
-                          be = bp[e][node];
+                        if (S == 1) // rows >= m: some finite entry of the (slack-padded) planes, dropped below
+                          be = (bp[e] + 4 * kk * nds)[sl];
                         else
-                          be = (i < m) ? coupling<S>(st, A.nn_max, npx, tr, m, line, i, dl, e - W) : 0.0;
+                          be = (4 * kk + og < m) ? coupling<S>(st, A.nn_max, npx, tr, m, line, 4 * kk + og, dl, e - W) : 0.0;
                         // rows outside [0,m) of the strip are zero: no range test on i + e - W
-                        v = fma(-(sc * be), xs[(i + e) * XST + c], v);
+                        v = fma(-(sc * be), xsl[(4 * kk + e) * XST], v);
                       }
-                    yop[kk] = (i < m) ? v : 0.0;
+                    yop[kk] = (4 * kk + og < m) ? v : 0.0;
                   }
                 SLOD_WAVE_SYNC(); // the strip is rewritten by the next line
 #pragma unroll
@@ -715,25 +727,29 @@ namespace
                   {
                     if (16 * ti >= m)
                       continue;
+                    // next tile row of V: this line's, or the first one of the next line
+                    if (ti + 1 < NT && 16 * (ti + 1) < m)
+                      load_V(vl, ti + 1, an);
+                    else if (t > 0)
+                      load_V(vg + (size_t)line_of(chain, t - 1) * vline, 0, an);
 #pragma unroll
                     for (int kk = 0; kk < NB; ++kk)
                       {
                         if (4 * kk >= m)
                           continue;
-                        const double av = (vl + (((kk >> 2) * NT + ti) * 4 + (kk & 3)) * 64)[lane];
-                        xn[ti]          = __builtin_amdgcn_mfma_f64_16x16x4f64(av, yop[kk], xn[ti], 0, 0, 0);
+                        xn[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], yop[kk], xn[ti], 0, 0, 0);
                       }
+#pragma unroll
+                    for (int kk = 0; kk < NB; ++kk)
+                      av[kk] = an[kk];
                   }
 #pragma unroll
                 for (int ti = 0; ti < NT; ++ti)
                   {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                      {
-                        const int row = 16 * ti + 4 * r + g;
-                        if (row < m && cok)
-                          xl[row * ncg + col] = xn[ti][r];
-                      }
+                      if (16 * ti + 4 * r + og < m && cok)
+                        (xl + (16 * ti + 4 * r) * ncg)[zl] = xn[ti][r];
                     xa[ti] = xn[ti];
                   }
               }
@@ -771,7 +787,7 @@ size_t slod_solve_mf_lds_bytes(int S, int m_max, int nc_max)
   if (NT == 0)
     return ~(size_t)0;
   const int    W = 2 * S - 1, BW = 2 * W + 1, MP = 16 * NT, BWP = BW + 1;
-  const int    bsz = ((MP + 2 * W) * BWP + 1) & ~1, PST = MP + 2, WST = MP + 1, WROWS = 16 + 2 * W;
+  const int    bsz = ((MP + 2 * W) * BWP + 1) & ~1, PST = MP + 2, WST = MP + 2 * W + 1, WROWS = 16 + 3 * W;
   const size_t chsz = (size_t)((4 * PST + WROWS * WST + 6 * bsz + 1) & ~1);
   size_t       n    = 2 * chsz;
   const size_t back = (size_t)4 * (MP + 2 * W) * 17; // backward strips alias the chain blocks

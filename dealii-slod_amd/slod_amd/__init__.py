@@ -48,9 +48,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise OSError("libslod_hip.so not built: run `make -C dealii-slod_amd` "
-                      "(or __graft_entry__.build()); there is no CPU fallback")
+    # tools/ may point at the timing-experiment build (lib/libslod_hip_diag.so, `make diag`)
+    path = os.environ.get("SLOD_LIB_PATH", LIB_PATH)
+    if not os.path.exists(path):
+        raise OSError("%s not built: run `make -C dealii-slod_amd` "
+                      "(or __graft_entry__.build()); there is no CPU fallback" % path)
     # One HIP runtime per process: PyTorch ships its own libamdhip64 (soname libamdhip64.so.7,
     # the same as /opt/rocm's).  If torch is imported AFTER this library, a second runtime
     # gets loaded and whichever initialises second sees no device.  Importing torch first
@@ -60,7 +62,7 @@ def load():
         import torch  # noqa: F401
     except ImportError:
         pass
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     vp, dp, u32p, u64p = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
     lib.slod_abi_version.restype = C.c_int
     lib.slod_last_error.restype = C.c_char_p
