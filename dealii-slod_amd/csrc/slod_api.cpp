@@ -556,8 +556,8 @@ int slod_plan_create(slod_handle *h, const uint32_t *gids, size_t n, const uint6
   // matching band coefficient is zero, or the result is dropped), so up to a few rows before the
   // first and after the last slot are touched.  X is zero-filled once: a skipped product must meet
   // a finite number.
-  p->guard = (size_t)8 * p->nc_max + 64;
-  const size_t st_slack = (size_t)p->nn_max;
+  p->guard = (size_t)24 * p->nc_max + 64;
+  const size_t st_slack = (size_t)4 * p->nn_max;
   ok       = ok && hipMalloc((void **)&p->ws_st, (p->chunk * p->st_stride + st_slack) * sizeof(double)) == hipSuccess;
   ok       = ok && hipMemset(p->ws_st, 0, (p->chunk * p->st_stride + st_slack) * sizeof(double)) == hipSuccess;
   ok       = ok && hipMalloc((void **)&p->ws_v, p->chunk * p->v_stride * sizeof(double)) == hipSuccess;

@@ -2,6 +2,8 @@
 #include "slod_assemble.hip.h"
 #include "slod_select.hip.h"
 
+#include <type_traits>
+
 namespace
 {
   // ---------------------------------------------------------------------------------
@@ -31,6 +33,25 @@ namespace
   __host__ __device__ constexpr int mf_min_waves(int NT, int S) { return NT <= 4 ? 2 : 1; }
 
   typedef double double2_t __attribute__((ext_vector_type(2)));
+
+// per-wave phase clocks of the timing-experiment build (tools/mf_timeline.py): cycles per phase,
+// summed over the lines, written to the patch's scratch block at the end
+#ifdef SLOD_ENABLE_DIAG
+#define SLOD_TMR(i)                       \
+  do                                      \
+    {                                     \
+      const long long now_ = clock64();   \
+      tq[i] += now_ - tlast;              \
+      tlast = now_;                       \
+    }                                     \
+  while (0)
+#else
+#define SLOD_TMR(i) \
+  do                \
+    {               \
+    }               \
+  while (0)
+#endif
 
 #define SLOD_WAVE_SYNC()                                        \
   do                                                            \
@@ -90,6 +111,10 @@ namespace
 
     if (SLOD_DG(A, (1 << 20)) && tid == 0)
       A.ms[(size_t)blockIdx.x * A.nc_max * A.nc_max] = (double)wall_clock64();
+#ifdef SLOD_ENABLE_DIAG
+    long long tq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = clock64();
+#endif
     // fused stencil assembly (scalar problems): the workgroup builds the planes of its own patch
     if (S == 1 && A.fuse_assemble)
       {
@@ -282,11 +307,18 @@ namespace
                              fma(w2, prd[2 * PST + 16 * ti], fma(w1, prd[PST + 16 * ti], w0 * prd[16 * ti])));
               // B operand: C[K,:], with C_KK - I in the pivot columns (so that C[J,K] <- C[J,K] W)
               vt[tk] -= (inK && og == oc3) ? 1.0 : 0.0;
+              // the tile row that holds the NEXT pivot rows goes first: the next block step can
+              // publish its panel while the other tile rows are still in the matrix pipe
+              constexpr int NBc = NB;
+              const int     tkn = (kb + 1 < NBc) ? (kb + 1) >> 2 : tk;
 #pragma unroll
-              for (int ti = 0; ti < NT; ++ti)
+              for (int tt = 0; tt < NT; ++tt)
+                {
+                  const int ti = (tt + tkn) % NT;
 #pragma unroll
-                for (int tj = 0; tj < NT; ++tj)
-                  acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[ti], vt[tj], acc[ti][tj], 0, 0, 0);
+                  for (int tj = 0; tj < NT; ++tj)
+                    acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[ti], vt[tj], acc[ti][tj], 0, 0, 0);
+                }
               // pivot rows: W C[K,:] = -U, and -W in the pivot block
               const double wsel = oc3 == 0 ? w0 : (oc3 == 1 ? w1 : (oc3 == 2 ? w2 : w3));
 #pragma unroll
@@ -409,14 +441,19 @@ namespace
           {
             if (t < nmy)
               {
+                SLOD_TMR(0);
                 sweep();
+                SLOD_TMR(1);
                 if (!SLOD_DG(A, 32768))
                   store_tiles(vg + (size_t)line_of(chain, t) * vline, -1.0);
+                SLOD_TMR(2);
                 // Schur complement of the next line (the meeting line after the last step)
                 if (!SLOD_DG(A, 16384))
                   next_S((t & 1) ? Tn1 : Tn0, Bbuf(Bc0, t), !(chain == 1 && t + 1 == nmy));
+                SLOD_TMR(3);
               }
             __syncthreads(); // A_t: V of step t is in the workspace, bands of step t+1 are in LDS
+            SLOD_TMR(4);
           }
         // the meeting line: chain 0 holds T_mid - W_0, chain 1 holds -W_1
         if (chain == 1)
@@ -477,58 +514,81 @@ namespace
         // B operand of Z = V R: rop[kk][t2] = R[4 kk + g][32 pass + 16 t2 + c],
         // R = (with_F ? F_line : 0) - Bprev^T Z(prev line) [+ rop]; Z from the workspace, no range
         // tests: outside [0,m) the band coefficient is zero and the workspace is guarded
-        auto build_rop = [&](double (&rop)[NB][2], int pass, int line, const double *Bprev, const double *zprev,
-                             bool with_F, bool add) __attribute__((always_inline)) {
+        // Branch-free over the k-steps (all NB of them: rows >= m are masked, their loads land in
+        // the guarded workspace): a branch per k-step would fence every group of loads behind its
+        // own wait.  WITH_Z = false for the first line of a chain.
+        auto build_rop = [&](auto with_z_c, double (&rop)[NB][2], int pass, int line, const double *Bprev,
+                             const double *zprev, bool with_F, bool add) __attribute__((always_inline)) {
+          constexpr bool WITH_Z = decltype(with_z_c)::value;
           const int      ol = olane(), og = ol >> 4, oc = ol & 15;
           const unsigned zl = (unsigned)(og * ncg + oc);              // lane part of a workspace address
           const double  *bcp = Bprev + og * BWP + 2 * W;              // B[i + e - W][i] = bcp[(4 kk + e) BWP - e]
-          const double  *zb  = zprev ? zprev - W * ncg + 32 * pass : nullptr;
+          const double  *zb  = zprev - W * ncg + 32 * pass;
           double         wL[2];
 #pragma unroll
           for (int t2 = 0; t2 < 2; ++t2)
             {
               const int j = line + 1 - kL[pass][t2];
-              wL[t2]      = (unsigned)j > (unsigned)n ? 0.0 : ((j == 0 || j == n) ? scF : 2.0 * scF);
+              wL[t2]      = (!with_F || (unsigned)j > (unsigned)n) ? 0.0 : ((j == 0 || j == n) ? scF : 2.0 * scF);
             }
+          const bool cok0 = 32 * pass + oc < nc, cok1 = 32 * pass + 16 + oc < nc;
+          // k-steps in groups of KG: first every workspace load of the group (independent, all in
+          // flight together), a scheduling fence, then the arithmetic.  Left to itself the compiler
+          // keeps each load next to its FMA and waits for them one by one.
+          constexpr int KG = (S == 1) ? 3 : 1;
 #pragma unroll
-          for (int kk = 0; kk < NB; ++kk)
+          for (int k0 = 0; k0 < NB; k0 += KG)
             {
-              if (4 * kk >= m || SLOD_DG(A, 2)) // wave-uniform
+              double zv[KG][2][BW];
+              if (WITH_Z)
                 {
-                  rop[kk][0] = rop[kk][1] = 0.0;
-                  continue;
+#pragma unroll
+                  for (int kq = 0; kq < KG; ++kq)
+#pragma unroll
+                    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                      for (int e = 0; e < BW; ++e)
+                        zv[kq][t2][e] = (k0 + kq < NB) ? (zb + (4 * (k0 + kq) + e) * ncg + 16 * t2)[zl] : 0.0;
+                  __builtin_amdgcn_sched_barrier(0);
                 }
-              double bc[BW];
 #pragma unroll
-              for (int e = 0; e < BW; ++e)
-                bc[e] = bcp[(4 * kk + e) * BWP - e];
-#pragma unroll
-              for (int t2 = 0; t2 < 2; ++t2)
+              for (int kq = 0; kq < KG; ++kq)
                 {
-                  double v = add ? rop[kk][t2] : 0.0;
-                  if (with_F)
+                  const int kk = k0 + kq;
+                  if (kk >= NB)
+                    continue;
+#pragma unroll
+                  for (int t2 = 0; t2 < 2; ++t2)
                     {
+                      double v = add ? rop[kk][t2] : 0.0;
                       if (S == 1)
                         v = fma(wL[t2], (double)(unsigned)((wcode[pass][t2] >> (2 * kk)) & 3u), v);
-                      else
+                      else if (with_F)
                         {
                           const int i = 4 * kk + og, pos = i / S, comp = i - pos * S;
                           const int ix = tr ? line + 1 : pos + 1, iy = tr ? pos + 1 : line + 1;
                           v += scF * pt_weight<S>(d, n, A.quirk, ix, iy, comp, min(32 * pass + 16 * t2 + oc, nc - 1));
                         }
-                    }
-                  if (zprev)
-                    {
+                      if (WITH_Z)
+                        {
 #pragma unroll
-                      for (int e = 0; e < BW; ++e)
-                        v = fma(-bc[e], (zb + (4 * kk + e) * ncg + 16 * t2)[zl], v);
+                          for (int e = 0; e < BW; ++e)
+                            v = fma(-bcp[(4 * kk + e) * BWP - e], zv[kq][t2][e], v);
+                        }
+                      rop[kk][t2] = (4 * kk + og < m && (t2 ? cok1 : cok0)) ? v : 0.0;
                     }
-                  const bool ok = 4 * kk + og < m && 32 * pass + 16 * t2 + oc < nc;
-                  rop[kk][t2]   = ok ? v : 0.0;
                 }
-              if (kk % 3 == 2)
-                __builtin_amdgcn_sched_barrier(0); // bounds the loads in flight (registers)
+              __builtin_amdgcn_sched_barrier(0);
             }
+        };
+        auto build_rop_z = [&](double (&rop)[NB][2], int pass, int line, const double *Bprev, const double *zprev,
+                               bool with_F, bool add) __attribute__((always_inline)) {
+          if (SLOD_DG(A, 2))
+            return;
+          if (zprev)
+            build_rop(std::true_type{}, rop, pass, line, Bprev, zprev, with_F, add);
+          else
+            build_rop(std::false_type{}, rop, pass, line, Bprev, zprev, with_F, add);
         };
         // Z(line) = V(line) R -> workspace; A operand = stored tiles of V (by symmetry)
         auto gemm_Z = [&](const double (&rop)[NB][2], int pass, int line) __attribute__((always_inline)) {
@@ -540,10 +600,17 @@ namespace
           const int      ol = olane(), og = ol >> 4, oc = ol & 15;
           const unsigned ul = (unsigned)ol, zl = (unsigned)(og * ncg + oc);
           double         av[NB], an[NB];
+          // k-steps in whole tiles (a branch per k-step would cut the MFMA stream into blocks):
+          // the operands of rows >= m are zero
           auto load_A = [&](int ti, double (&dst)[NB]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int kk = 0; kk < NB; ++kk)
-              dst[kk] = (4 * kk < m) ? (vl + (((kk >> 2) * NT + ti) * 4 + (kk & 3)) * 64)[ul] : 0.0;
+            for (int tk = 0; tk < NT; ++tk)
+              if (16 * tk < m)
+                {
+#pragma unroll
+                  for (int q = 0; q < 4; ++q)
+                    dst[4 * tk + q] = (vl + ((tk * NT + ti) * 4 + q) * 64)[ul];
+                }
           };
           load_A(0, av);
 #pragma unroll
@@ -555,14 +622,17 @@ namespace
                 load_A(ti + 1, an);
               double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-              for (int kk = 0; kk < NB; ++kk)
-                {
-                  if (4 * kk >= m)
-                    continue;
-                  acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], rop[kk][0], acc0, 0, 0, 0);
-                  if (two)
-                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], rop[kk][1], acc1, 0, 0, 0);
-                }
+              for (int tk = 0; tk < NT; ++tk)
+                if (16 * tk < m)
+                  {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                      {
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[4 * tk + q], rop[4 * tk + q][0], acc0, 0, 0, 0);
+                        if (two)
+                          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[4 * tk + q], rop[4 * tk + q][1], acc1, 0, 0, 0);
+                      }
+                  }
 #pragma unroll
               for (int r = 0; r < 4; ++r)
                 {
@@ -587,9 +657,12 @@ namespace
           for (int pass = 0; pass < 2; ++pass)
             if (pass < npass)
               {
-                build_rop(rop, pass, line, Bbuf(Bc0, t - 2),
-                          t > 1 ? xg + (size_t)line_of(chain, t - 2) * xline : nullptr, true, false);
+                SLOD_TMR(0);
+                build_rop_z(rop, pass, line, Bbuf(Bc0, t - 2),
+                            t > 1 ? xg + (size_t)line_of(chain, t - 2) * xline : nullptr, true, false);
+                SLOD_TMR(1);
                 gemm_Z(rop, pass, line);
+                SLOD_TMR(2);
               }
         };
         for (int t = 0; t < nstp; ++t)
@@ -598,7 +671,9 @@ namespace
               rz_line(t);
             if (t > 0 && !SLOD_DG(A, 32))
               put_step(t + 1, lane, 64); // bands the GJ wave needs after its next sweep
+            SLOD_TMR(3);
             __syncthreads(); // A_t
+            SLOD_TMR(4);
           }
         // R/Z of the last step (the shorter chain of an even L already did its last line in the loop)
         if (nmy == nstp && nmy > 0)
@@ -615,9 +690,9 @@ namespace
             for (int pass = 0; pass < 2; ++pass)
               if (pass < npass)
                 {
-                  build_rop(rop, pass, mid, B0, n0 > 0 ? xg + (size_t)(mid - 1) * xline : nullptr, true, false);
+                  build_rop_z(rop, pass, mid, B0, n0 > 0 ? xg + (size_t)(mid - 1) * xline : nullptr, true, false);
                   if (n1 > 0)
-                    build_rop(rop, pass, mid, B1, xg + (size_t)(mid + 1) * xline, false, true);
+                    build_rop_z(rop, pass, mid, B1, xg + (size_t)(mid + 1) * xline, false, true);
                   gemm_Z(rop, pass, mid); // X_mid
                 }
           }
@@ -663,8 +738,13 @@ namespace
             double av[NB], an[NB];
             auto   load_V = [&](const double *vl, int ti, double (&dst)[NB]) __attribute__((always_inline)) {
 #pragma unroll
-              for (int kk = 0; kk < NB; ++kk)
-                dst[kk] = (4 * kk < m) ? (vl + (((kk >> 2) * NT + ti) * 4 + (kk & 3)) * 64)[ul] : 0.0;
+              for (int tk = 0; tk < NT; ++tk)
+                if (16 * tk < m)
+                  {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                      dst[4 * tk + q] = (vl + ((tk * NT + ti) * 4 + q) * 64)[ul];
+                  }
             };
             load_V(vg + (size_t)line_of(chain, nmy - 1) * vline, 0, av);
             for (int t = nmy - 1; t >= 0; --t)
@@ -672,6 +752,7 @@ namespace
                 const int     line = line_of(chain, t);
                 const double *vl = vg + (size_t)line * vline;
                 double       *xl = xg + (size_t)line * xline + 16 * tj;
+                SLOD_TMR(5);
                 // X(prev) -> strip
 #pragma unroll
                 for (int ti = 0; ti < NT; ++ti)
@@ -699,29 +780,42 @@ namespace
                     bp[e]       = st + (size_t)((dy + 1) * 3 + dx + 1) * A.nn_max + nd0;
                   }
                 double yop[NB];
+                // groups of k-steps: all band loads of a group first, a scheduling fence, then the FMAs
+                constexpr int KGB = (S == 1) ? 6 : 1;
 #pragma unroll
-                for (int kk = 0; kk < NB; ++kk)
+                for (int k0 = 0; k0 < NB; k0 += KGB)
                   {
-                    if (4 * kk >= m)
-                      {
-                        yop[kk] = 0.0;
-                        continue;
-                      }
-                    double v = 0.0;
+                    double bev[KGB][BW];
 #pragma unroll
-                    for (int e = 0; e < BW; ++e)
+                    for (int kq = 0; kq < KGB; ++kq)
+#pragma unroll
+                      for (int e = 0; e < BW; ++e)
+                        {
+                          const int kk = k0 + kq;
+                          if (kk >= NB)
+                            bev[kq][e] = 0.0;
+                          else if (S == 1) // rows >= m: some finite entry of the (slack-padded) planes, dropped below
+                            bev[kq][e] = (bp[e] + 4 * kk * nds)[sl];
+                          else
+                            bev[kq][e] = (4 * kk + og < m) ? coupling<S>(st, A.nn_max, npx, tr, m, line, 4 * kk + og, dl, e - W) : 0.0;
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kq = 0; kq < KGB; ++kq)
                       {
-                        double be;
-                        if (S == 1) // rows >= m: some finite entry of the (slack-padded) planes, dropped below
-                          be = (bp[e] + 4 * kk * nds)[sl];
-                        else
-                          be = (4 * kk + og < m) ? coupling<S>(st, A.nn_max, npx, tr, m, line, 4 * kk + og, dl, e - W) : 0.0;
-                        // rows outside [0,m) of the strip are zero: no range test on i + e - W
-                        v = fma(-(sc * be), xsl[(4 * kk + e) * XST], v);
+                        const int kk = k0 + kq;
+                        if (kk >= NB)
+                          continue;
+                        double v = 0.0;
+#pragma unroll
+                        for (int e = 0; e < BW; ++e) // rows outside [0,m) of the strip are zero: no range test
+                          v = fma(-(sc * bev[kq][e]), xsl[(4 * kk + e) * XST], v);
+                        yop[kk] = (4 * kk + og < m) ? v : 0.0;
                       }
-                    yop[kk] = (4 * kk + og < m) ? v : 0.0;
+                    __builtin_amdgcn_sched_barrier(0);
                   }
                 SLOD_WAVE_SYNC(); // the strip is rewritten by the next line
+                SLOD_TMR(6);
 #pragma unroll
                 for (int ti = 0; ti < NT; ++ti)
                   {
@@ -733,12 +827,13 @@ namespace
                     else if (t > 0)
                       load_V(vg + (size_t)line_of(chain, t - 1) * vline, 0, an);
 #pragma unroll
-                    for (int kk = 0; kk < NB; ++kk)
-                      {
-                        if (4 * kk >= m)
-                          continue;
-                        xn[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], yop[kk], xn[ti], 0, 0, 0);
-                      }
+                    for (int tk = 0; tk < NT; ++tk)
+                      if (16 * tk < m)
+                        {
+#pragma unroll
+                          for (int q = 0; q < 4; ++q)
+                            xn[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[4 * tk + q], yop[4 * tk + q], xn[ti], 0, 0, 0);
+                        }
 #pragma unroll
                     for (int kk = 0; kk < NB; ++kk)
                       av[kk] = an[kk];
@@ -755,6 +850,12 @@ namespace
               }
           }
       }
+#ifdef SLOD_ENABLE_DIAG
+    SLOD_TMR(7);
+    if (SLOD_DG(A, (1 << 21)) && lane == 0 && A.nc_max * A.nc_max >= 48)
+      for (int i = 0; i < 8; ++i)
+        A.ms[(size_t)blockIdx.x * A.nc_max * A.nc_max + 16 + wave * 8 + i] = (double)tq[i];
+#endif
     // Fused selection stage: the same workgroup goes on with M, D, the boundary trace, the
     // least squares, phi and psi of its patch.
     const bool stamp = (SLOD_DG(A, (1 << 20))) && tid == 0 && A.nc_max * A.nc_max >= 12;
