@@ -37,16 +37,19 @@ bool slod_choose_solver(int S, int m_max, int nc_max, int nb_buf, int nf_max, si
   SlodSolveChoice c;
   c.debug = t.debug;
   // Kernel families:
+  //   tw   twisted + wave-specialised VALU Gauss-Jordan (default: fastest on every BASELINE size,
+  //        tools/solver_compare.py)
   //   mf   MFMA-factorised: blocked Gauss-Jordan on the fp64 matrix pipe, twisted, column-tile
-  //        private right-hand-side streams (default wherever it fits)
-  //   tw   twisted + wave-specialised VALU Gauss-Jordan
+  //        private right-hand-side streams (SLOD_SOLVE=mf; automatic only where tw does not fit)
   //   ws   wave-specialised, one chain
   //   coop all threads cooperate on every pivot (also for tiles narrower than the band)
   const int  wt = slod_solve_ws_tile(m_max);
   const bool ws_fits = wt > 0 && wt >= 2 * S - 1;
   const auto want = [&](int k) { return t.solver == 0 || t.solver == k; };
   const size_t lds_sel = slod_select_lds_bytes(S, nb_buf, nc_max, nf_max);
-  if (want(SLOD_K_MF) && slod_solve_mf_tiles(S, m_max) > 0 && slod_solve_mf_lds_bytes(S, m_max, nc_max) <= lds_max)
+  const bool   mf_fits = slod_solve_mf_tiles(S, m_max) > 0 && slod_solve_mf_lds_bytes(S, m_max, nc_max) <= lds_max;
+  const bool   tw_fits = ws_fits && slod_solve_tw_lds_bytes(S, m_max, nc_max) <= lds_max;
+  if (mf_fits && (t.solver == SLOD_K_MF || (t.solver == 0 && !tw_fits && !ws_fits)))
     {
       c.kind          = SLOD_K_MF;
       c.lds           = slod_solve_mf_lds_bytes(S, m_max, nc_max);
@@ -56,8 +59,7 @@ bool slod_choose_solver(int S, int m_max, int nc_max, int nb_buf, int nf_max, si
       if (c.fuse_select && lds_sel > c.lds)
         c.lds = lds_sel;
     }
-  else if (want(SLOD_K_TW) && (t.solver == SLOD_K_TW || wt <= 6) && ws_fits &&
-           slod_solve_tw_lds_bytes(S, m_max, nc_max) <= lds_max)
+  else if (want(SLOD_K_TW) && tw_fits)
     {
       c.kind          = SLOD_K_TW;
       c.lds           = slod_solve_tw_lds_bytes(S, m_max, nc_max);
@@ -69,7 +71,7 @@ bool slod_choose_solver(int S, int m_max, int nc_max, int nb_buf, int nf_max, si
       if (c.fuse_select && lds_sel > c.lds)
         c.lds = lds_sel;
     }
-  else if ((want(SLOD_K_WS) || t.solver == SLOD_K_TW) && (t.solver != 0 || wt <= 6) && ws_fits &&
+  else if ((want(SLOD_K_WS) || t.solver == SLOD_K_TW) && ws_fits &&
            slod_solve_ws_lds_bytes(S, m_max, nc_max) <= lds_max)
     {
       c.kind       = SLOD_K_WS;

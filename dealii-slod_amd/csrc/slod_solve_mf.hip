@@ -30,7 +30,7 @@ namespace
   // The patch matrix is scaled by a power of two so that its entries are <= 1: the sweep mixes
   // C with the identity (C_KK - I in the column update), harmless only at that scale.
   // ---------------------------------------------------------------------------------
-  __host__ __device__ constexpr int mf_min_waves(int NT, int S) { return NT <= 4 ? 2 : 1; }
+  __host__ __device__ constexpr int mf_min_waves(int NT, int S) { return NT <= 5 ? 2 : 1; }
 
   typedef double double2_t __attribute__((ext_vector_type(2)));
 
@@ -72,7 +72,8 @@ namespace
     constexpr int       PST = MP + 2;          // panel row stride (even: 16-byte aligned pivot block)
     constexpr int       WST = MP + 2 * W + 1, WROWS = 16 + 3 * W; // mixing window (+ W saved halo rows)
     constexpr int       XST = 17;              // backward strips: [MP + 2 W][16 + 1]
-    constexpr int       chsz = (4 * PST + WROWS * WST + 6 * bsz + 1) & ~1; // doubles per chain
+    constexpr int       TSC = 16 * 17;          // tile transposition scratch
+    constexpr int       chsz = (4 * PST + WROWS * WST + TSC + 6 * bsz + 1) & ~1; // doubles per chain
     const int           tid = threadIdx.x, lane = tid & 63;
     // the wave index is uniform: as a scalar the role branches are scalar branches and every
     // per-chain LDS / workspace base stays in SGPRs
@@ -90,7 +91,8 @@ namespace
     double *panel = cb;                  // [4][PST]      pivot rows of the current block step
     double *ywin  = panel + 4 * PST;     // [16 + 2 W][WST]  one tile row of V (+ halo rows / zero halo columns)
     double *yhs   = ywin + (16 + 2 * W) * WST; // [W][WST]    saved halo rows for the next tile row
-    double *Tf    = ywin + WROWS * WST;  // padded bands: T of the chain's first line,
+    double *tsc   = ywin + WROWS * WST;  // [16][17]      tile transposition scratch
+    double *Tf    = tsc + TSC;           // padded bands: T of the chain's first line,
     double *Tn0   = Tf + bsz;            //   T bands of the steps (by step parity),
     double *Tn1   = Tn0 + bsz;
     double *Bc0   = Tn1 + bsz;           //   coupling bands of the steps (by step mod 3)
@@ -159,6 +161,33 @@ namespace
     // write the (zero padded) bands of `line`, scaled: T (within the line; zero band if !with_T)
     // and the coupling line -> line + dl of this chain; t0/nt = caller's thread slice
     auto put_bands = [&](int line, double *Tdst, bool with_T, double *Bdst, int t0, int nt) __attribute__((always_inline)) {
+      if (S == 1)
+        {
+          // scalar problems: entry (i, o) of a band is ONE stencil plane value at node(i) = nd0 + i nds,
+          // plane (dy+1)*3 + dx+1 with (dx,dy) = (o, dlb) or transposed; a thread takes whole rows:
+          // its BW loads are independent and go out together
+          const int     dlb = Tdst ? 0 : dl;
+          double       *dst = Tdst ? Tdst : Bdst;
+          const int     nd0 = tr ? (line + 1) + npx : 1 + (line + 1) * npx, nds = tr ? npx : 1;
+          const double *pl[BW];
+#pragma unroll
+          for (int e = 0; e < BW; ++e)
+            {
+              const int o = e - W, dx = tr ? dlb : o, dy = tr ? o : dlb;
+              pl[e]       = st + (size_t)((dy + 1) * 3 + dx + 1) * A.nn_max + nd0;
+            }
+          for (int i = t0; i < m; i += nt)
+            {
+              double v[BW];
+#pragma unroll
+              for (int e = 0; e < BW; ++e)
+                v[e] = pl[e][i * nds];
+#pragma unroll
+              for (int e = 0; e < BW; ++e)
+                dst[(i + W) * BWP + e] = (with_T && (unsigned)(i + e - W) < (unsigned)m) ? sc * v[e] : 0.0;
+            }
+          return;
+        }
       for (int idx = t0; idx < m * BW; idx += nt)
         {
           const int i = idx / BW, oi = idx - i * BW, o = oi - W;
@@ -192,15 +221,21 @@ namespace
     // address and mask of the unrolled code out of the line loops and spills them, and a reload
     // from scratch sits on the dependent chain.  Redoing them costs one or two VALU each.
     auto olane = [&]() __attribute__((always_inline)) {
-      int l = lane;
-      asm volatile("" : "+v"(l));
-      return l;
+      // v_mbcnt on an opaque zero: three VALU, nothing kept alive between uses (a copy of `lane`
+      // would itself be spilled and reloaded on the dependent chain)
+      int z = 0;
+      asm volatile("" : "+v"(z));
+      return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, (unsigned)z));
     };
     if (is_gj)
       {
         __builtin_amdgcn_s_setprio(3);
-        double4_t acc[NT][NT];
-        bool      bad = false;
+        // S_l is symmetric: only the tiles ti <= tj are kept (NT (NT + 1) / 2 accumulators);
+        // wherever a lower tile would be read, its mirror is read transposed through LDS.
+        constexpr int NU = NT * (NT + 1) / 2;
+        double4_t     acc[NU];
+        bool          bad = false;
+#define UT(ti, tj) ((ti) * NT - ((ti) * ((ti) - 1)) / 2 + (tj) - (ti))
 
         // entry (16 ti + 4 r + g, 16 tj + c) of a padded T band buffer, |ti - tj| <= 1: element
         // 16 ti BWP + toff[tj - ti + 1][r] (column BW of a band row is a zero pad); identity on
@@ -236,10 +271,10 @@ namespace
 #pragma unroll
           for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
-            for (int tj = 0; tj < NT; ++tj)
+            for (int tj = ti; tj < NT; ++tj)
 #pragma unroll
               for (int r = 0; r < 4; ++r)
-                acc[ti][tj][r] = t_entry(Tsrc, toff, og, oc, ti, tj, r, pad_identity);
+                acc[UT(ti, tj)][r] = t_entry(Tsrc, toff, og, oc, ti, tj, r, pad_identity);
         };
 
         // blocked symmetric sweep of all pivots < m: acc <- -S^-1 (padding: -1 / identity, decoupled)
@@ -252,16 +287,29 @@ namespace
               const int  tk = kb >> 2, q = kb & 3;
               const int  ol = olane(), og = ol >> 4, oc = ol & 15, oc3 = ol & 3;
               const bool inK = (oc >> 2) == q;
-              // pivot rows -> panel (they are the B operand C[K,:] already)
+              // pivot rows C[K,:] -> panel.  Columns right of the pivot tile: register q of tile row tk
+              // (the B operand already); columns left of it: column K of the tiles above, transposed
               double  vt[NT];
               double *pwr = panel + og * PST + oc;
 #pragma unroll
-              for (int tj = 0; tj < NT; ++tj)
+              for (int tj = tk; tj < NT; ++tj)
                 {
-                  vt[tj]       = acc[tk][tj][q];
+                  vt[tj]       = acc[UT(tk, tj)][q];
                   pwr[16 * tj] = vt[tj];
                 }
+              if (inK)
+                {
+                  double *pwt = panel + oc3 * PST + og;
+#pragma unroll
+                  for (int tj = 0; tj < tk; ++tj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                      pwt[16 * tj + 4 * r] = acc[UT(tj < tk ? tj : tk, tk)][r];
+                }
               SLOD_WAVE_SYNC();
+#pragma unroll
+              for (int tj = 0; tj < tk; ++tj)
+                vt[tj] = pwr[16 * tj];
               // pivot block (uniform addresses), upper triangle
               const double2_t *pb  = reinterpret_cast<const double2_t *>(panel + 16 * tk + 4 * q);
               const double2_t  r00 = pb[0], r01 = pb[1];
@@ -316,48 +364,91 @@ namespace
                 {
                   const int ti = (tt + tkn) % NT;
 #pragma unroll
-                  for (int tj = 0; tj < NT; ++tj)
-                    acc[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[ti], vt[tj], acc[ti][tj], 0, 0, 0);
+                  for (int tj = ti; tj < NT; ++tj)
+                    acc[UT(ti, tj)] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[ti], vt[tj], acc[UT(ti, tj)], 0, 0, 0);
                 }
               // pivot rows: W C[K,:] = -U, and -W in the pivot block
               const double wsel = oc3 == 0 ? w0 : (oc3 == 1 ? w1 : (oc3 == 2 ? w2 : w3));
 #pragma unroll
-              for (int tj = 0; tj < NT; ++tj)
-                acc[tk][tj][q] = (tj == tk && inK) ? -wsel : -u[tj];
+              for (int tj = tk; tj < NT; ++tj)
+                acc[UT(tk, tj)][q] = (tj == tk && inK) ? -wsel : -u[tj];
             }
         };
 
-        // acc = -V_l  ->  acc = T_next - B^T V_l B = T_next + B^T acc B   (B = coupling l -> l+1).
-        // Both banded products go through a small LDS window, one tile row at a time and in place:
-        // rows first (Y = B^T acc needs the W rows above and below: halo rows of the window), then
-        // columns (Y B needs the W columns left and right: the window has zero halo columns).
+        // acc = -V_l  ->  acc = T_next - B^T V_l B = T_next + B^T acc B   (B = coupling l -> l+1),
+        // upper tiles only, in place, one tile row at a time from the LAST to the first (so that the
+        // transposed tiles a tile row reads are still un-mixed), through an LDS window with absolute
+        // column indices [W + j]: rows first (B^T acc: needs the W rows above and below -- halo rows --
+        // and, for the tile left of the diagonal, the mirror of the tile above), then columns.
         auto next_S = [&](const double *Tsrc, const double *Bl, bool pad_identity) __attribute__((always_inline)) {
 #pragma unroll
-          for (int ti = 0; ti < NT; ++ti)
+          for (int tt = 0; tt < NT; ++tt)
             {
+              const int ti = NT - 1 - tt, tl = ti > 0 ? ti - 1 : 0;
               const int ol = olane(), og = ol >> 4, oc = ol & 15;
               int       toff[3][4];
               t_offsets(og, oc, toff);
-              // ---- rows.  upper halo: the un-mixed last W rows of the previous tile row (saved in yhs)
-              for (int x = ol; x < W * WST; x += 64)
-                ywin[x] = ti > 0 ? yhs[x] : 0.0;
-              double *yw = ywin + (og + W) * WST + oc + W; // own row 4 r + g, column c of a tile
-#pragma unroll
-              for (int tj = 0; tj < NT; ++tj)
+              double *wrow = ywin + (og + W) * WST + W + oc; // own row 4 r + g, column c of tile 0
+              // ---- fill for the row mixing, columns of the tiles >= tl
+              if (ti > 0)
                 {
+                  // upper halo: the last W rows of tile row ti - 1 (un-mixed: not processed yet)
+                  if (og >= 4 - W)
+                    {
+#pragma unroll
+                      for (int tj = tl; tj < NT; ++tj)
+                        ywin[(og - (4 - W)) * WST + W + 16 * tj + oc] = acc[UT(tl, tj)][3];
+                    }
+                  // own rows, tile left of the diagonal: the mirror of tile (ti - 1, ti)
 #pragma unroll
                   for (int r = 0; r < 4; ++r)
-                    yw[4 * r * WST + 16 * tj] = acc[ti][tj][r];
-                  if (og < W) // lower halo: the first W rows of the next tile row
-                    yw[16 * WST + 16 * tj] = ti + 1 < NT ? acc[ti + 1 < NT ? ti + 1 : ti][tj][0] : 0.0;
+                    ywin[(oc + W) * WST + W + 16 * tl + 4 * r + og] = acc[UT(tl, ti)][r];
+                }
+              else
+                for (int x = ol; x < W * WST; x += 64)
+                  ywin[x] = 0.0;
+#pragma unroll
+              for (int tj = ti; tj < NT; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                  wrow[4 * r * WST + 16 * tj] = acc[UT(ti, tj)][r];
+              if (ti + 1 < NT)
+                {
+                  // lower halo: the first W rows of tile row ti + 1, un-mixed: saved when that row was
+                  // processed (columns >= 16 (ti + 1)); mirrors of the tiles (ti, ti + 1) and (ti - 1, ti + 1)
+                  // for the columns of the diagonal tile and of the tile left of it
+                  if (og < W)
+                    {
+#pragma unroll
+                      for (int tj = ti + 1; tj < NT; ++tj)
+                        ywin[(16 + W + og) * WST + W + 16 * tj + oc] = yhs[og * WST + W + 16 * tj + oc];
+                    }
+                  if (oc < W) // columns of the diagonal tile (and of the tile left of it): mirrors
+                    {
+#pragma unroll
+                      for (int r = 0; r < 4; ++r)
+                        {
+                          ywin[(16 + W + oc) * WST + W + 16 * ti + 4 * r + og] = acc[UT(ti, ti + 1 < NT ? ti + 1 : ti)][r];
+                          if (ti > 0)
+                            ywin[(16 + W + oc) * WST + W + 16 * tl + 4 * r + og] = acc[UT(tl, ti + 1 < NT ? ti + 1 : ti)][r];
+                        }
+                    }
+                }
+              else
+                for (int x = ol; x < W * WST; x += 64)
+                  ywin[(16 + W) * WST + x] = 0.0;
+              if (og < W) // the first rows of this tile row, for the tile row above
+                {
+#pragma unroll
+                  for (int tj = ti; tj < NT; ++tj)
+                    yhs[og * WST + W + 16 * tj + oc] = acc[UT(ti, tj)][0];
                 }
               SLOD_WAVE_SYNC();
-              if (ti + 1 < NT)
-                for (int x = ol; x < W * WST; x += 64)
-                  yhs[x] = ywin[16 * WST + x];
+              // ---- rows: Y[i][j] = sum_e B[i + e - W][i] acc[i + e - W][j]
+              double4_t yl = {0.0, 0.0, 0.0, 0.0};
               {
                 const double *rbp = Bl + og * BWP + 2 * W;       // B[i + e - W][i] = rbp[(16 ti + 4 r + e) BWP - e]
-                const double *yr  = ywin + og * WST + oc + W;     // acc[i + e - W][j] = yr[(4 r + e) WST + 16 tj]
+                const double *yr  = ywin + og * WST + W + oc;     // acc[i + e - W][j] = yr[(4 r + e) WST + 16 tj]
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                   {
@@ -365,31 +456,45 @@ namespace
 #pragma unroll
                     for (int e = 0; e < BW; ++e)
                       rb[e] = rbp[(16 * ti + 4 * r + e) * BWP - e];
-#pragma unroll
-                    for (int tj = 0; tj < NT; ++tj)
+                    if (ti > 0)
                       {
-                        double v = rb[W] * acc[ti][tj][r];
+                        double v = 0.0;
+#pragma unroll
+                        for (int e = 0; e < BW; ++e)
+                          v = fma(rb[e], yr[(4 * r + e) * WST + 16 * tl], v);
+                        yl[r] = v;
+                      }
+#pragma unroll
+                    for (int tj = ti; tj < NT; ++tj)
+                      {
+                        double v = rb[W] * acc[UT(ti, tj)][r];
 #pragma unroll
                         for (int e = 0; e < BW; ++e)
                           if (e != W)
                             v = fma(rb[e], yr[(4 * r + e) * WST + 16 * tj], v);
-                        acc[ti][tj][r] = v;
+                        acc[UT(ti, tj)][r] = v;
                       }
                   }
               }
               SLOD_WAVE_SYNC(); // every read of the un-mixed rows precedes the rewrite
               // ---- columns: acc[i][j] = T[i][j] + sum_f Y[i][j + f - W] B[j + f - W][j]
+              if (ti > 0)
+                {
 #pragma unroll
-              for (int tj = 0; tj < NT; ++tj)
+                  for (int r = 0; r < 4; ++r)
+                    wrow[4 * r * WST + 16 * tl] = yl[r];
+                }
+#pragma unroll
+              for (int tj = ti; tj < NT; ++tj)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                  yw[4 * r * WST + 16 * tj] = acc[ti][tj][r];
+                  wrow[4 * r * WST + 16 * tj] = acc[UT(ti, tj)][r];
               SLOD_WAVE_SYNC();
               {
                 const double *cbp = Bl + oc * BWP + 2 * W;          // B[j + f - W][j] = cbp[(16 tj + f) BWP - f]
                 const double *yc  = ywin + (og + W) * WST + oc;      // Y[i][j + f - W] = yc[4 r WST + 16 tj + f]
 #pragma unroll
-                for (int tj = 0; tj < NT; ++tj)
+                for (int tj = ti; tj < NT; ++tj)
                   {
                     double cbv[BW];
 #pragma unroll
@@ -398,12 +503,12 @@ namespace
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                       {
-                        double v = fma(cbv[W], acc[ti][tj][r], t_entry(Tsrc, toff, og, oc, ti, tj, r, pad_identity));
+                        double v = fma(cbv[W], acc[UT(ti, tj)][r], t_entry(Tsrc, toff, og, oc, ti, tj, r, pad_identity));
 #pragma unroll
                         for (int f = 0; f < BW; ++f)
                           if (f != W)
                             v = fma(cbv[f], yc[4 * r * WST + 16 * tj + f], v);
-                        acc[ti][tj][r] = v;
+                        acc[UT(ti, tj)][r] = v;
                       }
                   }
               }
@@ -411,18 +516,39 @@ namespace
             }
         };
 
-        // tiles <-> workspace (accumulator layout: 512-byte coalesced per register)
-        auto store_tiles = [&](double *dst, double sign) __attribute__((always_inline)) {
+        // tiles -> workspace in the accumulator layout (512-byte coalesced per register).  Upper tiles
+        // from the registers; store_full adds the mirrors below the diagonal (the GEMMs of the
+        // helpers read every tile as the A operand), transposed through a 16 x 17 LDS scratch.
+        auto store_upper = [&](double *dst, double sign) __attribute__((always_inline)) {
           const unsigned ul = (unsigned)olane();
 #pragma unroll
           for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
-            for (int tj = 0; tj < NT; ++tj)
+            for (int tj = ti; tj < NT; ++tj)
               {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                  (dst + ((ti * NT + tj) * 4 + r) * 64)[ul] = sign * acc[ti][tj][r]; // uniform base + lane
-                __builtin_amdgcn_sched_barrier(0); // one tile at a time: no 36 negated copies in flight
+                  (dst + ((ti * NT + tj) * 4 + r) * 64)[ul] = sign * acc[UT(ti, tj)][r]; // uniform base + lane
+                __builtin_amdgcn_sched_barrier(0);
+              }
+        };
+        auto store_full = [&](double *dst, double sign) __attribute__((always_inline)) {
+          store_upper(dst, sign);
+          const int      ol = olane(), og = ol >> 4, oc = ol & 15;
+          const unsigned ul = (unsigned)ol;
+#pragma unroll
+          for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int tj = ti + 1; tj < NT; ++tj)
+              {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                  tsc[oc * 17 + 4 * r + og] = sign * acc[UT(ti, tj)][r];
+                SLOD_WAVE_SYNC();
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                  (dst + ((tj * NT + ti) * 4 + r) * 64)[ul] = tsc[(4 * r + og) * 17 + oc];
+                SLOD_WAVE_SYNC();
               }
         };
 
@@ -430,10 +556,8 @@ namespace
         if (chain == 1 && nmy == 0)
           {
 #pragma unroll
-            for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-              for (int tj = 0; tj < NT; ++tj)
-                acc[ti][tj] = double4_t{0.0, 0.0, 0.0, 0.0};
+            for (int k = 0; k < NU; ++k)
+              acc[k] = double4_t{0.0, 0.0, 0.0, 0.0};
           }
         else
           t_init(Tf, true);
@@ -445,7 +569,7 @@ namespace
                 sweep();
                 SLOD_TMR(1);
                 if (!SLOD_DG(A, 32768))
-                  store_tiles(vg + (size_t)line_of(chain, t) * vline, -1.0);
+                  store_full(vg + (size_t)line_of(chain, t) * vline, -1.0);
                 SLOD_TMR(2);
                 // Schur complement of the next line (the meeting line after the last step)
                 if (!SLOD_DG(A, 16384))
@@ -455,9 +579,9 @@ namespace
             __syncthreads(); // A_t: V of step t is in the workspace, bands of step t+1 are in LDS
             SLOD_TMR(4);
           }
-        // the meeting line: chain 0 holds T_mid - W_0, chain 1 holds -W_1
+        // the meeting line: chain 0 holds T_mid - W_0, chain 1 holds -W_1 (upper tiles)
         if (chain == 1)
-          store_tiles(vg + (size_t)mid * vline, 1.0);
+          store_upper(vg + (size_t)mid * vline, 1.0);
         __syncthreads(); // M1: chain 1's contribution is in the workspace
         if (chain == 0)
           {
@@ -466,16 +590,17 @@ namespace
 #pragma unroll
             for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
-              for (int tj = 0; tj < NT; ++tj)
+              for (int tj = ti; tj < NT; ++tj)
                 {
 #pragma unroll
                   for (int r = 0; r < 4; ++r)
-                    acc[ti][tj][r] += (w1 + ((ti * NT + tj) * 4 + r) * 64)[ul];
+                    acc[UT(ti, tj)][r] += (w1 + ((ti * NT + tj) * 4 + r) * 64)[ul];
                   __builtin_amdgcn_sched_barrier(0);
                 }
             sweep();
-            store_tiles(vg + (size_t)mid * vline, -1.0);
+            store_full(vg + (size_t)mid * vline, -1.0);
           }
+#undef UT
         if (bad && lane == 0 && !SLOD_DG(A, -1))
           atomicOr(A.status, 1);
         __builtin_amdgcn_s_setprio(0);
@@ -485,124 +610,80 @@ namespace
     else
       {
         // ===== helper wave of the chain: right-hand sides of the line one step behind =====
-        // Column tile pair `pass` = columns 32 pass .. 32 pass + 31.  Per pass and half (t2), line
-        // invariant: cell origin across the lines (kL) and the along-the-line weight pattern of
-        // P^T as 2-bit codes per k-step (0, 1, 2 = the weights themselves).
-        int      kL[2][2];
-        unsigned long long wcode[2][2];
-        {
-          const int g0 = lane >> 4, c0 = lane & 15;
-#pragma unroll
-          for (int pass = 0; pass < 2; ++pass)
-#pragma unroll
-            for (int t2 = 0; t2 < 2; ++t2)
-              {
-                const int cc  = min(32 * pass + 16 * t2 + c0, nc - 1);
-                const int kxn = colk[cc] * n, kyn = colk[A.nc_max + cc] * n;
-                kL[pass][t2]  = tr ? kxn : kyn;
-                const int kA  = tr ? kyn : kxn;
-                unsigned long long code = 0;
-                if (S == 1)
-                  for (int kk = 0; kk < NB; ++kk)
-                    {
-                      const int j = 4 * kk + g0 + 1 - kA;
-                      code |= (unsigned long long)((unsigned)j > (unsigned)n ? 0u : ((j == 0 || j == n) ? 1u : 2u)) << (2 * kk);
-                    }
-                wcode[pass][t2] = code;
-              }
-        }
-        // B operand of Z = V R: rop[kk][t2] = R[4 kk + g][32 pass + 16 t2 + c],
+        // One 16-column tile of Z at a time (runtime loop: the code of a line exists once).
+        // B operand of Z = V R: rop[kk] = R[4 kk + g][16 tj + c],
         // R = (with_F ? F_line : 0) - Bprev^T Z(prev line) [+ rop]; Z from the workspace, no range
-        // tests: outside [0,m) the band coefficient is zero and the workspace is guarded
-        // Branch-free over the k-steps (all NB of them: rows >= m are masked, their loads land in
-        // the guarded workspace): a branch per k-step would fence every group of loads behind its
-        // own wait.  WITH_Z = false for the first line of a chain.
-        auto build_rop = [&](auto with_z_c, double (&rop)[NB][2], int pass, int line, const double *Bprev,
-                             const double *zprev, bool with_F, bool add) __attribute__((always_inline)) {
-          constexpr bool WITH_Z = decltype(with_z_c)::value;
+        // tests: outside [0,m) the band coefficient is zero and the workspace is guarded (a line
+        // without predecessor passes a zero band and any valid line as zprev).
+        // Branch-free over the k-steps (all NB of them: rows >= m are masked): a branch per k-step
+        // would fence every group of loads behind its own wait.
+        auto build_rop = [&](double (&rop)[NB], int tj, int line, const double *Bprev, const double *zprev,
+                             bool with_F, bool add) __attribute__((always_inline)) {
+          if (SLOD_DG(A, 2))
+            return;
           const int      ol = olane(), og = ol >> 4, oc = ol & 15;
           const unsigned zl = (unsigned)(og * ncg + oc);              // lane part of a workspace address
           const double  *bcp = Bprev + og * BWP + 2 * W;              // B[i + e - W][i] = bcp[(4 kk + e) BWP - e]
-          const double  *zb  = zprev - W * ncg + 32 * pass;
-          double         wL[2];
-#pragma unroll
-          for (int t2 = 0; t2 < 2; ++t2)
-            {
-              const int j = line + 1 - kL[pass][t2];
-              wL[t2]      = (!with_F || (unsigned)j > (unsigned)n) ? 0.0 : ((j == 0 || j == n) ? scF : 2.0 * scF);
-            }
-          const bool cok0 = 32 * pass + oc < nc, cok1 = 32 * pass + 16 + oc < nc;
+          const double  *zb  = zprev - W * ncg + 16 * tj;
+          const bool     cok = 16 * tj + oc < nc;
+          // scalar problems: F = scale * w(across the lines) * w(along the line), w = 1 / 2 / 0
+          const int    cc  = min(16 * tj + oc, nc - 1);
+          const int    kxn = colk[cc] * n, kyn = colk[A.nc_max + cc] * n;
+          const int    jl  = line + 1 - (tr ? kxn : kyn);
+          const double wL  = (!with_F || (unsigned)jl > (unsigned)n) ? 0.0 : ((jl == 0 || jl == n) ? scF : 2.0 * scF);
+          const int    ja  = og + 1 - (tr ? kyn : kxn);                // + 4 kk = node offset along the line
           // k-steps in groups of KG: first every workspace load of the group (independent, all in
           // flight together), a scheduling fence, then the arithmetic.  Left to itself the compiler
           // keeps each load next to its FMA and waits for them one by one.
-          constexpr int KG = (S == 1) ? 3 : 1;
+          constexpr int KG = (S == 1) ? 4 : 1;
 #pragma unroll
           for (int k0 = 0; k0 < NB; k0 += KG)
             {
-              double zv[KG][2][BW];
-              if (WITH_Z)
-                {
+              double zv[KG][BW];
 #pragma unroll
-                  for (int kq = 0; kq < KG; ++kq)
+              for (int kq = 0; kq < KG; ++kq)
 #pragma unroll
-                    for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-                      for (int e = 0; e < BW; ++e)
-                        zv[kq][t2][e] = (k0 + kq < NB) ? (zb + (4 * (k0 + kq) + e) * ncg + 16 * t2)[zl] : 0.0;
-                  __builtin_amdgcn_sched_barrier(0);
-                }
+                for (int e = 0; e < BW; ++e)
+                  zv[kq][e] = (k0 + kq < NB) ? (zb + (4 * (k0 + kq) + e) * ncg)[zl] : 0.0;
+              __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
               for (int kq = 0; kq < KG; ++kq)
                 {
                   const int kk = k0 + kq;
                   if (kk >= NB)
                     continue;
-#pragma unroll
-                  for (int t2 = 0; t2 < 2; ++t2)
+                  double v = add ? rop[kk] : 0.0;
+                  if (S == 1)
                     {
-                      double v = add ? rop[kk][t2] : 0.0;
-                      if (S == 1)
-                        v = fma(wL[t2], (double)(unsigned)((wcode[pass][t2] >> (2 * kk)) & 3u), v);
-                      else if (with_F)
-                        {
-                          const int i = 4 * kk + og, pos = i / S, comp = i - pos * S;
-                          const int ix = tr ? line + 1 : pos + 1, iy = tr ? pos + 1 : line + 1;
-                          v += scF * pt_weight<S>(d, n, A.quirk, ix, iy, comp, min(32 * pass + 16 * t2 + oc, nc - 1));
-                        }
-                      if (WITH_Z)
-                        {
-#pragma unroll
-                          for (int e = 0; e < BW; ++e)
-                            v = fma(-bcp[(4 * kk + e) * BWP - e], zv[kq][t2][e], v);
-                        }
-                      rop[kk][t2] = (4 * kk + og < m && (t2 ? cok1 : cok0)) ? v : 0.0;
+                      const int j = ja + 4 * kk;
+                      v = fma(wL, (unsigned)j > (unsigned)n ? 0.0 : ((j == 0 || j == n) ? 1.0 : 2.0), v);
                     }
+                  else if (with_F)
+                    {
+                      const int i = 4 * kk + og, pos = i / S, comp = i - pos * S;
+                      const int ix = tr ? line + 1 : pos + 1, iy = tr ? pos + 1 : line + 1;
+                      v += scF * pt_weight<S>(d, n, A.quirk, ix, iy, comp, cc);
+                    }
+#pragma unroll
+                  for (int e = 0; e < BW; ++e)
+                    v = fma(-bcp[(4 * kk + e) * BWP - e], zv[kq][e], v);
+                  rop[kk] = (4 * kk + og < m && cok) ? v : 0.0;
                 }
               __builtin_amdgcn_sched_barrier(0);
             }
         };
-        auto build_rop_z = [&](double (&rop)[NB][2], int pass, int line, const double *Bprev, const double *zprev,
-                               bool with_F, bool add) __attribute__((always_inline)) {
-          if (SLOD_DG(A, 2))
-            return;
-          if (zprev)
-            build_rop(std::true_type{}, rop, pass, line, Bprev, zprev, with_F, add);
-          else
-            build_rop(std::false_type{}, rop, pass, line, Bprev, zprev, with_F, add);
-        };
         // Z(line) = V(line) R -> workspace; A operand = stored tiles of V (by symmetry)
-        auto gemm_Z = [&](const double (&rop)[NB][2], int pass, int line) __attribute__((always_inline)) {
+        auto gemm_Z = [&](const double (&rop)[NB], int tj, int line) __attribute__((always_inline)) {
           if (SLOD_DG(A, 8))
             return;
-          const double  *vl  = vg + (size_t)line * vline;
-          double        *xl  = xg + (size_t)line * xline + 32 * pass;
-          const bool     two = 2 * pass + 1 < nct;
+          const double  *vl = vg + (size_t)line * vline;
+          double        *xl = xg + (size_t)line * xline + 16 * tj;
           const int      ol = olane(), og = ol >> 4, oc = ol & 15;
           const unsigned ul = (unsigned)ol, zl = (unsigned)(og * ncg + oc);
-          double         av[NB], an[NB];
-          // k-steps in whole tiles (a branch per k-step would cut the MFMA stream into blocks):
-          // the operands of rows >= m are zero
-          auto load_A = [&](int ti, double (&dst)[NB]) __attribute__((always_inline)) {
+          // k-steps in whole tiles, the last tile k-step by k-step (operands of rows >= m are zero);
+          // the A tiles of the next tile row are fetched while the MFMAs of this one run
+          double av[NB], an[NB];
+          auto   load_A = [&](int ti, double (&dst)[NB]) __attribute__((always_inline)) {
 #pragma unroll
             for (int tk = 0; tk < NT; ++tk)
               if (16 * tk < m)
@@ -620,81 +701,75 @@ namespace
                 continue;
               if (ti + 1 < NT && 16 * (ti + 1) < m)
                 load_A(ti + 1, an);
-              double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+              double4_t acc0 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
               for (int tk = 0; tk < NT; ++tk)
-                if (16 * tk < m)
+                if (16 * tk + 16 <= m)
                   {
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                      {
-                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[4 * tk + q], rop[4 * tk + q][0], acc0, 0, 0, 0);
-                        if (two)
-                          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[4 * tk + q], rop[4 * tk + q][1], acc1, 0, 0, 0);
-                      }
+                      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[4 * tk + q], rop[4 * tk + q], acc0, 0, 0, 0);
+                  }
+                else if (16 * tk < m)
+                  {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                      if (16 * tk + 4 * q < m)
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[4 * tk + q], rop[4 * tk + q], acc0, 0, 0, 0);
                   }
 #pragma unroll
               for (int r = 0; r < 4; ++r)
-                {
-                  const int  row = 16 * ti + 4 * r + og, col = 32 * pass + oc;
-                  double    *xr  = xl + (16 * ti + 4 * r) * ncg;
-                  if (row < m && col < nc)
-                    xr[zl] = acc0[r];
-                  if (two && row < m && col + 16 < nc)
-                    (xr + 16)[zl] = acc1[r];
-                }
+                if (16 * ti + 4 * r + og < m && 16 * tj + oc < nc)
+                  (xl + (16 * ti + 4 * r) * ncg)[zl] = acc0[r];
 #pragma unroll
               for (int kk = 0; kk < NB; ++kk)
                 av[kk] = an[kk];
             }
         };
-        double rop[NB][2];
-        auto   rz_line = [&](int t) __attribute__((always_inline)) {
-          // RHS block and Z of line(t-1): its V became visible at A_{t-1}; the coupling
-          // line(t-2) -> line(t-1) is the B band of step t-2
-          const int line = line_of(chain, t - 1);
-#pragma unroll
-          for (int pass = 0; pass < 2; ++pass)
-            if (pass < npass)
-              {
-                SLOD_TMR(0);
-                build_rop_z(rop, pass, line, Bbuf(Bc0, t - 2),
-                            t > 1 ? xg + (size_t)line_of(chain, t - 2) * xline : nullptr, true, false);
-                SLOD_TMR(1);
-                gemm_Z(rop, pass, line);
-                SLOD_TMR(2);
-              }
-        };
-        for (int t = 0; t < nstp; ++t)
+        double rop[NB];
+        // zero band for a line without predecessor: the B buffer of "step -1" is never written
+        // before step 1 has been processed (LDS starts zeroed)
+        for (int t = 0; t <= nstp; ++t)
           {
+            // RHS block and Z of line(t-1): its V became visible at A_{t-1}; the coupling
+            // line(t-2) -> line(t-1) is the B band of step t-2.  t == nstp: the last step (the
+            // shorter chain of an even L already did its last line inside the loop)
             if (t > 0 && t - 1 < nmy)
-              rz_line(t);
+              {
+                const int line = line_of(chain, t - 1);
+                for (int tj = 0; tj < nct; ++tj)
+                  {
+                    SLOD_TMR(0);
+                    build_rop(rop, tj, line, Bbuf(Bc0, t - 2), xg + (size_t)line_of(chain, t > 1 ? t - 2 : t - 1) * xline,
+                              true, false);
+                    SLOD_TMR(1);
+                    gemm_Z(rop, tj, line);
+                    SLOD_TMR(2);
+                  }
+              }
+            if (t == nstp)
+              break;
             if (t > 0 && !SLOD_DG(A, 32))
               put_step(t + 1, lane, 64); // bands the GJ wave needs after its next sweep
             SLOD_TMR(3);
             __syncthreads(); // A_t
             SLOD_TMR(4);
           }
-        // R/Z of the last step (the shorter chain of an even L already did its last line in the loop)
-        if (nmy == nstp && nmy > 0)
-          rz_line(nstp);
         __syncthreads(); // M1 (also: both chains' last Z are in the workspace)
         __syncthreads(); // M2: V_mid is in the workspace
         if (chain == 0)
           {
             // R_mid = F_mid - B^T Z(mid-1) - B'^T Z(mid+1); the bands are the last B of each chain
+            // (zero bands if a chain has no line)
             const double *B0 = Bbuf(Bc0, n0 - 1);
-            double       *ob = ocb + 4 * PST + WROWS * WST + 3 * bsz; // other chain's Bc0
+            double       *ob = ocb + 4 * PST + WROWS * WST + TSC + 3 * bsz; // other chain's Bc0
             const double *B1 = Bbuf(ob, n1 - 1);
-#pragma unroll
-            for (int pass = 0; pass < 2; ++pass)
-              if (pass < npass)
-                {
-                  build_rop_z(rop, pass, mid, B0, n0 > 0 ? xg + (size_t)(mid - 1) * xline : nullptr, true, false);
-                  if (n1 > 0)
-                    build_rop_z(rop, pass, mid, B1, xg + (size_t)(mid + 1) * xline, false, true);
-                  gemm_Z(rop, pass, mid); // X_mid
-                }
+            for (int tj = 0; tj < nct; ++tj)
+              {
+                build_rop(rop, tj, mid, B0, xg + (size_t)(n0 > 0 ? mid - 1 : mid) * xline, true, false);
+                build_rop(rop, tj, mid, B1, xg + (size_t)(n1 > 0 ? mid + 1 : mid) * xline, false, true);
+                gemm_Z(rop, tj, mid); // X_mid
+              }
           }
         __syncthreads(); // M3
       }
@@ -703,7 +778,7 @@ namespace
     // from the meeting line outwards.  Wave (chain, w) owns the column tiles w, w + 2 of its chain:
     // X(line) = Z(line) - V(line) (B X(prev)), X(prev) kept in the accumulator layout and, for the
     // banded product, in a wave-private LDS strip with W zero rows above and below -- no workgroup
-    // barrier, no re-read of X.  V tiles are fetched one tile row ahead (across lines too).
+    // barrier, no re-read of X.
     if (nmy > 0 && !SLOD_DG(A, 16))
       {
         constexpr int XROWS = MP + 2 * W;
@@ -719,24 +794,22 @@ namespace
         const int nds = tr ? npx : 1;
         for (int tj = w2; tj < nct; tj += 2)
           {
-            const int      ol = olane(), og = ol >> 4, oc = ol & 15;
-            const unsigned ul = (unsigned)ol, zl = (unsigned)(og * ncg + oc), sl = (unsigned)(og * nds);
-            const bool     cok = 16 * tj + oc < nc;
-            double        *xsl = xs + og * XST + oc; // strip row 4 r + g - W ... of this lane
-            double4_t      xa[NT];
+            double4_t xa[NT]; // X(prev), then Z(line), then X(line)
             {
-              const double *xm = xg + (size_t)mid * xline + 16 * tj;
+              const int      ol = olane(), og = ol >> 4, oc = ol & 15;
+              const unsigned zl = (unsigned)(og * ncg + oc);
+              const double  *xm = xg + (size_t)mid * xline + 16 * tj;
 #pragma unroll
               for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                   {
                     const double v = (xm + (16 * ti + 4 * r) * ncg)[zl];
-                    xa[ti][r]      = (16 * ti + 4 * r + og < m && cok) ? v : 0.0;
+                    xa[ti][r]      = (16 * ti + 4 * r + og < m && 16 * tj + oc < nc) ? v : 0.0;
                   }
             }
             double av[NB], an[NB];
-            auto   load_V = [&](const double *vl, int ti, double (&dst)[NB]) __attribute__((always_inline)) {
+            auto   load_V = [&](const double *vl, int ti, unsigned ul, double (&dst)[NB]) __attribute__((always_inline)) {
 #pragma unroll
               for (int tk = 0; tk < NT; ++tk)
                 if (16 * tk < m)
@@ -746,28 +819,30 @@ namespace
                       dst[4 * tk + q] = (vl + ((tk * NT + ti) * 4 + q) * 64)[ul];
                   }
             };
-            load_V(vg + (size_t)line_of(chain, nmy - 1) * vline, 0, av);
+            load_V(vg + (size_t)line_of(chain, nmy - 1) * vline, 0, (unsigned)olane(), av);
             for (int t = nmy - 1; t >= 0; --t)
               {
-                const int     line = line_of(chain, t);
-                const double *vl = vg + (size_t)line * vline;
-                double       *xl = xg + (size_t)line * xline + 16 * tj;
+                const int      line = line_of(chain, t);
+                const double  *vl = vg + (size_t)line * vline;
+                double        *xl = xg + (size_t)line * xline + 16 * tj;
+                const int      ol = olane(), og = ol >> 4, oc = ol & 15;
+                const unsigned ul = (unsigned)ol, zl = (unsigned)(og * ncg + oc), sl = (unsigned)(og * nds);
+                const bool     cok = 16 * tj + oc < nc;
+                double        *xsl = xs + og * XST + oc; // strip row 4 r + g - W ... of this lane
                 SLOD_TMR(5);
-                // X(prev) -> strip
+                // X(prev) -> strip; then the registers take Z(line), the start of the accumulators
 #pragma unroll
                 for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
                   for (int r = 0; r < 4; ++r)
                     xsl[(16 * ti + 4 * r + W) * XST] = xa[ti][r];
-                // Z(line): start of the accumulators (independent loads, issued early)
-                double4_t xn[NT];
 #pragma unroll
                 for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
                   for (int r = 0; r < 4; ++r)
                     {
                       const double v = (xl + (16 * ti + 4 * r) * ncg)[zl];
-                      xn[ti][r]      = (16 * ti + 4 * r + og < m && cok) ? v : 0.0;
+                      xa[ti][r]      = (16 * ti + 4 * r + og < m && cok) ? v : 0.0;
                     }
                 SLOD_WAVE_SYNC();
                 // B operand: -(B X(prev))[4 kk + g][col], B = coupling line -> prev (stencil planes)
@@ -781,7 +856,7 @@ namespace
                   }
                 double yop[NB];
                 // groups of k-steps: all band loads of a group first, a scheduling fence, then the FMAs
-                constexpr int KGB = (S == 1) ? 6 : 1;
+                constexpr int KGB = (S == 1) ? 4 : 1;
 #pragma unroll
                 for (int k0 = 0; k0 < NB; k0 += KGB)
                   {
@@ -823,16 +898,23 @@ namespace
                       continue;
                     // next tile row of V: this line's, or the first one of the next line
                     if (ti + 1 < NT && 16 * (ti + 1) < m)
-                      load_V(vl, ti + 1, an);
+                      load_V(vl, ti + 1, ul, an);
                     else if (t > 0)
-                      load_V(vg + (size_t)line_of(chain, t - 1) * vline, 0, an);
+                      load_V(vg + (size_t)line_of(chain, t - 1) * vline, 0, ul, an);
 #pragma unroll
                     for (int tk = 0; tk < NT; ++tk)
-                      if (16 * tk < m)
+                      if (16 * tk + 16 <= m)
                         {
 #pragma unroll
                           for (int q = 0; q < 4; ++q)
-                            xn[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[4 * tk + q], yop[4 * tk + q], xn[ti], 0, 0, 0);
+                            xa[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[4 * tk + q], yop[4 * tk + q], xa[ti], 0, 0, 0);
+                        }
+                      else if (16 * tk < m)
+                        {
+#pragma unroll
+                          for (int q = 0; q < 4; ++q)
+                            if (16 * tk + 4 * q < m)
+                              xa[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[4 * tk + q], yop[4 * tk + q], xa[ti], 0, 0, 0);
                         }
 #pragma unroll
                     for (int kk = 0; kk < NB; ++kk)
@@ -840,13 +922,10 @@ namespace
                   }
 #pragma unroll
                 for (int ti = 0; ti < NT; ++ti)
-                  {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                      if (16 * ti + 4 * r + og < m && cok)
-                        (xl + (16 * ti + 4 * r) * ncg)[zl] = xn[ti][r];
-                    xa[ti] = xn[ti];
-                  }
+                  for (int r = 0; r < 4; ++r)
+                    if (16 * ti + 4 * r + og < m && cok)
+                      (xl + (16 * ti + 4 * r) * ncg)[zl] = xa[ti][r];
               }
           }
       }
@@ -889,7 +968,7 @@ size_t slod_solve_mf_lds_bytes(int S, int m_max, int nc_max)
     return ~(size_t)0;
   const int    W = 2 * S - 1, BW = 2 * W + 1, MP = 16 * NT, BWP = BW + 1;
   const int    bsz = ((MP + 2 * W) * BWP + 1) & ~1, PST = MP + 2, WST = MP + 2 * W + 1, WROWS = 16 + 3 * W;
-  const size_t chsz = (size_t)((4 * PST + WROWS * WST + 6 * bsz + 1) & ~1);
+  const size_t chsz = (size_t)((4 * PST + WROWS * WST + 16 * 17 + 6 * bsz + 1) & ~1);
   size_t       n    = 2 * chsz;
   const size_t back = (size_t)4 * (MP + 2 * W) * 17; // backward strips alias the chain blocks
   if (back > n)

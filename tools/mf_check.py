@@ -17,7 +17,9 @@ def run(kw, dist, maxp=12, solve_only=False):
     fields = [so.fill_coefficient(20250614 + f, d, lo, hi, g.NE) for f in range(kw.get("spacedim", 1))]
     for f, a in enumerate(fields):
         g.set_coefficient(f, a)
-    ids = sample_ids(g)[:maxp]
+    allids = sample_ids(g)
+    full = [p for p in allids if g.patch_layout(int(p)).mx == g.patch_layout(int(p)).my == 2 * kw['oversampling'] + 1][:3]
+    ids = np.array(sorted(set(list(allids[:maxp - 3]) + full)), dtype=np.uint32)
     worst_x = worst_p = 0.0
     t0 = time.time()
     for pid in ids[:4]:
