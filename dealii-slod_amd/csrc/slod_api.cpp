@@ -2,10 +2,7 @@
 // Implements include/slod.h.  No CPU fallback exists: every compute entry point needs a
 // HIP device and fails with SLOD_ERR_DEVICE otherwise.
 // only the C-ABI of include/slod.h is exported (the library is built with -fvisibility=hidden)
-#pragma GCC visibility push(default)
-#include "../../include/slod.h"
-#pragma GCC visibility pop
-#include "slod_device.h"
+#include "slod_host.h"
 
 #include <algorithm>
 #include <cmath>
@@ -17,8 +14,6 @@
 
 namespace
 {
-  thread_local std::string g_create_error;
-
   struct PatchGeom
   {
     int cx, cy, x0, y0, mx, my;
@@ -26,19 +21,11 @@ namespace
   };
 } // namespace
 
-struct slod_handle
+std::string &slod_create_error()
 {
-  slod_config         cfg;
-  int                 N  = 0; // coarse cells per side
-  int                 NE = 0; // fine elements per side
-  int                 NP = 0; // patches per problem
-  int                 first_full = -1;
-  double             *d_coef[2]  = {nullptr, nullptr};
-  std::vector<char>   coef_set;  // [problem*2 + field]
-  hipStream_t         stream = nullptr;
-  bool                device_ready = false; // stream and coefficient storage exist
-  mutable std::string error;
-};
+  static thread_local std::string e;
+  return e;
+}
 
 struct slod_plan
 {
@@ -66,19 +53,8 @@ struct slod_plan
 
 namespace
 {
-  int fail(const slod_handle *h, int code, const std::string &msg)
-  {
-    if (h)
-      h->error = msg;
-    else
-      g_create_error = msg;
-    return code;
-  }
-
-  int hip_fail(const slod_handle *h, hipError_t e, const char *what)
-  {
-    return fail(h, SLOD_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
-  }
+  int fail(const slod_handle *h, int code, const std::string &msg) { return slod_fail(h, code, msg); }
+  int hip_fail(const slod_handle *h, hipError_t e, const char *what) { return slod_hip_fail(h, e, what); }
 
   // Morton order of hyper_cube + refine_global (x in the even bits), or row-major for a
   // non-2^k grid.  Reference: patches are stored in active-cell order (LOD.cc:184-192).
@@ -200,7 +176,11 @@ namespace
   }
 
   // stream + coefficient storage; called by every entry point that touches the device
-  int ensure_device(slod_handle *h)
+  int ensure_device(slod_handle *h) { return slod_ensure_device(h); }
+} // namespace
+
+int slod_ensure_device(slod_handle *h)
+{
   {
     if (h->device_ready)
       return SLOD_OK;
@@ -230,7 +210,10 @@ namespace
     h->device_ready = true;
     return SLOD_OK;
   }
+}
 
+namespace
+{
   SlodKernelArgs make_args(const slod_plan *p, size_t first, double *d_basis, double *d_premult)
   {
     const slod_handle *h = p->h;
@@ -280,7 +263,7 @@ int slod_abi_version(void) { return SLOD_ABI_VERSION; }
 
 const char *slod_last_error(const slod_handle *h)
 {
-  return h ? h->error.c_str() : g_create_error.c_str();
+  return h ? h->error.c_str() : slod_create_error().c_str();
 }
 
 int slod_create(const slod_config *cfg, slod_handle **out)

@@ -1,0 +1,611 @@
+// Consumers and producers either side of the per-patch basis construction:
+//   * the global LOD system  A_LOD = C^T (A C),  C^T f,  its solve and the fine-scale
+//     reconstruction  (reference assemble_global_matrix LOD.cc:860-973, solve :976-1002, :1251);
+//   * patch descriptors and coefficient sampling evaluated on the device
+//     (create_patches / create_mesh_for_patch LOD.cc:122-244,770-858; problem_parameter::value
+//     Diffusion.h:40-53 at the points of quadrature_fine, Diffusion.h:154).
+// Everything is index arithmetic on the patch-lexicographic layout of include/slod.h: the overlap of
+// two patches is a rectangle of global fine nodes.  These kernels are HBM/L2-bound gathers and
+// reductions (no MFMA shape in them); one wave per patch pair keeps every reduction inside a wave.
+#include "slod_host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace
+{
+  // ---- index calculus shared by host and device (mirrors patch_geom() of slod_api.cpp) ----
+  __host__ __device__ inline void grid_centre(const SlodGrid &G, uint32_t pid, int &cx, int &cy)
+  {
+    if (G.morton_bits < 0)
+      {
+        cx = (int)(pid % (uint32_t)G.N);
+        cy = (int)(pid / (uint32_t)G.N);
+        return;
+      }
+    cx = cy = 0;
+    for (int b = 0; b < G.morton_bits; ++b)
+      {
+        cx |= (int)((pid >> (2 * b)) & 1u) << b;
+        cy |= (int)((pid >> (2 * b + 1)) & 1u) << b;
+      }
+  }
+  __host__ __device__ inline uint32_t grid_pid(const SlodGrid &G, int cx, int cy)
+  {
+    if (G.morton_bits < 0)
+      return (uint32_t)(cx + G.N * cy);
+    uint32_t p = 0;
+    for (int b = 0; b < G.morton_bits; ++b)
+      p |= ((uint32_t)((cx >> b) & 1) << (2 * b)) | ((uint32_t)((cy >> b) & 1) << (2 * b + 1));
+    return p;
+  }
+  struct Extent
+  {
+    int x0, y0, mx, my; // coarse cells
+  };
+  __host__ __device__ inline Extent grid_extent(const SlodGrid &G, int cx, int cy)
+  {
+    Extent    e;
+    const int l = G.oversampling;
+    e.x0        = cx - l > 0 ? cx - l : 0;
+    e.y0        = cy - l > 0 ? cy - l : 0;
+    const int x1 = cx + l < G.N - 1 ? cx + l : G.N - 1, y1 = cy + l < G.N - 1 ? cy + l : G.N - 1;
+    e.mx         = x1 - e.x0 + 1;
+    e.my         = y1 - e.y0 + 1;
+    return e;
+  }
+
+  // ---------------------------------------------------------------------------------
+  // A_LOD block rows.  Block = one row patch p, wave w = the candidate neighbours j = w, w+4, ...
+  // (offsets of the centre cell in [-(2l+1), 2l+1]^2: patches further apart share no node).
+  // ---------------------------------------------------------------------------------
+  __global__ __launch_bounds__(256) void k_lod_matrix(const SlodGrid G, const uint32_t *rows, const double *basis,
+                                                     const double *premult, size_t stride, double *values,
+                                                     uint32_t *cols)
+  {
+    const int      lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int      s = G.spacedim, n = G.n_sub, span = 4 * G.oversampling + 3, cap = span * span;
+    const uint32_t p = rows[blockIdx.x];
+    int            pcx, pcy;
+    grid_centre(G, p, pcx, pcy);
+    const Extent  pe = grid_extent(G, pcx, pcy);
+    const int     pnx = pe.mx * n + 1, pny = pe.my * n + 1, pnf = s * pnx * pny;
+    const double *phi = basis + (size_t)p * stride;
+    for (int j = wave; j < cap; j += 4)
+      {
+        const int    qcx = pcx + j % span - (span / 2), qcy = pcy + j / span - (span / 2);
+        const size_t out = (size_t)blockIdx.x * cap + j;
+        if (qcx < 0 || qcx >= G.N || qcy < 0 || qcy >= G.N)
+          {
+            if (lane == 0)
+              cols[out] = 0xffffffffu;
+            if (lane < s * s)
+              values[out * s * s + lane] = 0.0;
+            continue;
+          }
+        const uint32_t q  = grid_pid(G, qcx, qcy);
+        const Extent   qe = grid_extent(G, qcx, qcy);
+        const int      qnx = qe.mx * n + 1, qny = qe.my * n + 1, qnf = s * qnx * qny;
+        // overlap in global fine-node coordinates (inclusive)
+        const int xa = max(pe.x0, qe.x0) * n, xb = min(pe.x0 + pe.mx, qe.x0 + qe.mx) * n;
+        const int ya = max(pe.y0, qe.y0) * n, yb = min(pe.y0 + pe.my, qe.y0 + qe.my) * n;
+        const int w = xb - xa + 1, hgt = yb - ya + 1;
+        double    acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+        if (w > 0 && hgt > 0)
+          {
+            const double *psi = premult + (size_t)q * stride;
+            for (int idx = lane; idx < w * hgt; idx += 64)
+              {
+                const int iy = idx / w, ix = idx - iy * w;
+                const int np = (xa + ix - pe.x0 * n) + (ya + iy - pe.y0 * n) * pnx;
+                const int nq = (xa + ix - qe.x0 * n) + (ya + iy - qe.y0 * n) * qnx;
+                for (int c = 0; c < s; ++c)
+                  for (int d = 0; d < s; ++d)
+                    {
+                      const double ph = phi[(size_t)d * pnf + s * np + c];
+                      for (int e = 0; e < s; ++e)
+                        acc[d][e] = fma(ph, psi[(size_t)e * qnf + s * nq + c], acc[d][e]);
+                    }
+              }
+          }
+        for (int d = 0; d < s; ++d)
+          for (int e = 0; e < s; ++e)
+            {
+              double v = acc[d][e];
+              for (int off = 32; off > 0; off >>= 1)
+                v += __shfl_xor(v, off, 64);
+              if (lane == 0)
+                values[out * s * s + d * s + e] = v;
+            }
+        if (lane == 0)
+          cols[out] = (w > 0 && hgt > 0) ? q : 0xffffffffu;
+      }
+  }
+
+  // C^T f for the row patches: block = one patch, all its nodes
+  __global__ __launch_bounds__(256) void k_lod_rhs(const SlodGrid G, const uint32_t *rows, const double *basis,
+                                                  size_t stride, const double *frhs, double *out)
+  {
+    __shared__ double red[4][2];
+    const int         s = G.spacedim, n = G.n_sub, NEp = G.N * n + 1;
+    const uint32_t    p = rows[blockIdx.x];
+    int               pcx, pcy;
+    grid_centre(G, p, pcx, pcy);
+    const Extent  pe = grid_extent(G, pcx, pcy);
+    const int     pnx = pe.mx * n + 1, pny = pe.my * n + 1, pnf = s * pnx * pny;
+    const double *phi = basis + (size_t)p * stride;
+    double        acc[2] = {0.0, 0.0};
+    for (int node = threadIdx.x; node < pnx * pny; node += 256)
+      {
+        const int iy = node / pnx, ix = node - iy * pnx;
+        const int gn = (pe.x0 * n + ix) + (pe.y0 * n + iy) * NEp;
+        for (int c = 0; c < s; ++c)
+          {
+            const double f = frhs[(size_t)gn * s + c];
+            for (int d = 0; d < s; ++d)
+              acc[d] = fma(phi[(size_t)d * pnf + s * node + c], f, acc[d]);
+          }
+      }
+    for (int d = 0; d < s; ++d)
+      {
+        double v = acc[d];
+        for (int off = 32; off > 0; off >>= 1)
+          v += __shfl_xor(v, off, 64);
+        if ((threadIdx.x & 63) == 0)
+          red[threadIdx.x >> 6][d] = v;
+      }
+    __syncthreads();
+    if (threadIdx.x < s)
+      out[(size_t)blockIdx.x * s + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] +
+                                                  red[3][threadIdx.x];
+  }
+
+  // u_fine = C u_H: one thread per global fine node, gather over the patches that contain it
+  __global__ __launch_bounds__(256) void k_lod_reconstruct(const SlodGrid G, const double *basis, size_t stride,
+                                                          const double *u, double *fine)
+  {
+    const int s = G.spacedim, n = G.n_sub, NEp = G.N * n + 1, l = G.oversampling;
+    const int gn = blockIdx.x * 256 + threadIdx.x;
+    if (gn >= NEp * NEp)
+      return;
+    const int X = gn % NEp, Y = gn / NEp;
+    // cells whose closure contains the node, widened by the oversampling
+    const int cxl = max((X + n - 1) / n - 1 - l, 0), cxh = min(X / n + l, G.N - 1);
+    const int cyl = max((Y + n - 1) / n - 1 - l, 0), cyh = min(Y / n + l, G.N - 1);
+    double    acc[2] = {0.0, 0.0};
+    for (int cy = cyl; cy <= cyh; ++cy)
+      for (int cx = cxl; cx <= cxh; ++cx)
+        {
+          const Extent e = grid_extent(G, cx, cy);
+          const int    ix = X - e.x0 * n, iy = Y - e.y0 * n;
+          if (ix < 0 || ix > e.mx * n || iy < 0 || iy > e.my * n)
+            continue;
+          const uint32_t p   = grid_pid(G, cx, cy);
+          const int      pnx = e.mx * n + 1, pnf = s * pnx * (e.my * n + 1);
+          const double  *phi = basis + (size_t)p * stride;
+          for (int d = 0; d < s; ++d)
+            {
+              const double ud = u[(size_t)p * s + d];
+              for (int c = 0; c < s; ++c)
+                acc[c] = fma(phi[(size_t)d * pnf + s * (ix + iy * pnx) + c], ud, acc[c]);
+            }
+        }
+    for (int c = 0; c < s; ++c)
+      fine[(size_t)gn * s + c] = acc[c];
+  }
+
+  // ---- Jacobi-preconditioned CG on the block rows (device scalars: no host round trip per step)
+  struct CgScalars
+  {
+    double rz, pAp, rz_new, rr, rhs2;
+  };
+  __global__ void k_cg_spmv_dot(int nrow, int s, int cap, const double *values, const uint32_t *cols, const double *x,
+                                double *y, CgScalars *sc)
+  {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double    part = 0.0;
+    if (i < nrow)
+      {
+        const int p = i / s, d = i - p * s;
+        double    acc = 0.0;
+        for (int j = 0; j < cap; ++j)
+          {
+            const uint32_t q = cols[(size_t)p * cap + j];
+            if (q == 0xffffffffu)
+              continue;
+            for (int e = 0; e < s; ++e)
+              acc = fma(values[((size_t)p * cap + j) * s * s + d * s + e], x[(size_t)q * s + e], acc);
+          }
+        y[i] = acc;
+        part = acc * x[i];
+      }
+    for (int off = 32; off > 0; off >>= 1)
+      part += __shfl_xor(part, off, 64);
+    if ((threadIdx.x & 63) == 0 && part != 0.0)
+      atomicAdd(&sc->pAp, part);
+  }
+  __global__ void k_cg_init(int nrow, int s, int cap, const double *values, const uint32_t *cols, const double *rhs,
+                            double *x, double *r, double *z, double *pv, double *dinv, CgScalars *sc)
+  {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double    a = 0.0, b = 0.0;
+    if (i < nrow)
+      {
+        const int p = i / s, d = i - p * s;
+        double    diag = 1.0;
+        for (int j = 0; j < cap; ++j)
+          if (cols[(size_t)p * cap + j] == (uint32_t)p)
+            diag = values[((size_t)p * cap + j) * s * s + d * s + d];
+        dinv[i] = diag != 0.0 ? 1.0 / diag : 1.0;
+        x[i]    = 0.0;
+        r[i]    = rhs[i];
+        z[i]    = dinv[i] * rhs[i];
+        pv[i]   = z[i];
+        a       = r[i] * z[i];
+        b       = r[i] * r[i];
+      }
+    for (int off = 32; off > 0; off >>= 1)
+      {
+        a += __shfl_xor(a, off, 64);
+        b += __shfl_xor(b, off, 64);
+      }
+    if ((threadIdx.x & 63) == 0)
+      {
+        atomicAdd(&sc->rz, a);
+        atomicAdd(&sc->rhs2, b);
+        atomicAdd(&sc->rr, b);
+      }
+  }
+  __global__ void k_cg_update_xr(int nrow, const double *pv, const double *Ap, const double *dinv, double *x, double *r,
+                                 double *z, CgScalars *sc)
+  {
+    const int    i = blockIdx.x * 256 + threadIdx.x;
+    const double alpha = sc->pAp != 0.0 ? sc->rz / sc->pAp : 0.0;
+    double       a = 0.0, b = 0.0;
+    if (i < nrow)
+      {
+        x[i] = fma(alpha, pv[i], x[i]);
+        r[i] = fma(-alpha, Ap[i], r[i]);
+        z[i] = dinv[i] * r[i];
+        a    = r[i] * z[i];
+        b    = r[i] * r[i];
+      }
+    for (int off = 32; off > 0; off >>= 1)
+      {
+        a += __shfl_xor(a, off, 64);
+        b += __shfl_xor(b, off, 64);
+      }
+    if ((threadIdx.x & 63) == 0)
+      {
+        atomicAdd(&sc->rz_new, a);
+        atomicAdd(&sc->rr, b);
+      }
+  }
+  __global__ void k_cg_update_p(int nrow, const double *z, double *pv, const CgScalars *sc)
+  {
+    const int    i = blockIdx.x * 256 + threadIdx.x;
+    const double beta = sc->rz != 0.0 ? sc->rz_new / sc->rz : 0.0;
+    if (i < nrow)
+      pv[i] = fma(beta, pv[i], z[i]);
+  }
+  __global__ void k_cg_rotate(CgScalars *sc)
+  {
+    sc->rz     = sc->rz_new;
+    sc->rz_new = 0.0;
+    sc->pAp    = 0.0;
+    sc->rr     = 0.0;
+  }
+
+  // ---- inputs produced on the device ----
+  __global__ void k_patch_info(const SlodGrid G, const uint32_t *ids, int n_ids, slod_patch_info *out)
+  {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_ids)
+      return;
+    const int n = G.n_sub, s = G.spacedim;
+    int       cx, cy;
+    grid_centre(G, ids[k], cx, cy);
+    const Extent    e = grid_extent(G, cx, cy);
+    slod_patch_info info;
+    info.cx             = cx;
+    info.cy             = cy;
+    info.x0             = e.x0;
+    info.y0             = e.y0;
+    info.mx             = e.mx;
+    info.my             = e.my;
+    info.nx             = n * e.mx;
+    info.ny             = n * e.my;
+    info.side_domain[0] = e.x0 == 0;                // LOD.cc:830-843: id 0 on the domain boundary
+    info.side_domain[1] = e.x0 + e.mx == G.N;
+    info.side_domain[2] = e.y0 == 0;
+    info.side_domain[3] = e.y0 + e.my == G.N;
+    info.n_fine         = s * (info.nx + 1) * (info.ny + 1);
+    info.n_internal     = s * (info.nx - 1) * (info.ny - 1);
+    info.n_coarse       = s * e.mx * e.my;
+    // id-99 nodes, corners shared with an id-0 side included (LODtools.h:367-369)
+    const int side = !info.side_domain[0] + !info.side_domain[1];
+    int       nb   = (info.ny - 1) * side;
+    nb += info.side_domain[2] ? side : info.nx + 1;
+    nb += info.side_domain[3] ? side : info.nx + 1;
+    info.n_boundary = s * nb;
+    info.is_lod     = !G.lod_stabilization || G.oversampling == 0 || e.mx * e.my == G.N * G.N; // LOD.cc:563-564
+    out[k]          = info;
+  }
+
+  __global__ void k_sample_coefficient(int NE, const double *vals, int r, double *coef)
+  {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)NE * NE * 4)
+      return;
+    const int    q = (int)(i & 3);
+    const size_t el = i >> 2;
+    const int    ex = (int)(el % (size_t)NE), ey = (int)(el / (size_t)NE);
+    const double g0 = 0.21132486540518711775, g1 = 0.78867513459481288225; // QGauss<1>(2)
+    const double hf = 1.0 / (double)NE;
+    const double x = (ex + ((q & 1) ? g1 : g0)) * hf, y = (ey + ((q & 2) ? g1 : g0)) * hf;
+    const int    NC = 1 << r;
+    const double eta = 1.0 / (double)NC;
+    // Diffusion.h:47-51
+    const int idx = (int)floor(x / eta) + NC * (int)floor(y / eta);
+    coef[i]       = vals[idx];
+  }
+} // namespace
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+int slod_lod_row_capacity(const slod_handle *h)
+{
+  if (!h)
+    return SLOD_ERR_ARGUMENT;
+  const int span = 4 * h->cfg.oversampling + 3;
+  return span * span;
+}
+
+int slod_lod_pattern(const slod_handle *h, uint32_t patch_id, uint32_t *neighbours, size_t capacity)
+{
+  if (!h || !neighbours)
+    return SLOD_ERR_ARGUMENT;
+  if (patch_id >= (uint32_t)h->NP)
+    return slod_fail(h, SLOD_ERR_ARGUMENT, "slod_lod_pattern: patch id out of range");
+  const SlodGrid G = slod_grid_of(h);
+  int            cx, cy;
+  grid_centre(G, patch_id, cx, cy);
+  const Extent          pe = grid_extent(G, cx, cy);
+  std::vector<uint32_t> nb;
+  const int             half = 2 * h->cfg.oversampling + 1;
+  for (int dy = -half; dy <= half; ++dy)
+    for (int dx = -half; dx <= half; ++dx)
+      {
+        const int qx = cx + dx, qy = cy + dy;
+        if (qx < 0 || qx >= h->N || qy < 0 || qy >= h->N)
+          continue;
+        const Extent qe = grid_extent(G, qx, qy);
+        if (std::max(pe.x0, qe.x0) > std::min(pe.x0 + pe.mx, qe.x0 + qe.mx) ||
+            std::max(pe.y0, qe.y0) > std::min(pe.y0 + pe.my, qe.y0 + qe.my))
+          continue;
+        nb.push_back(grid_pid(G, qx, qy));
+      }
+  std::sort(nb.begin(), nb.end());
+  if (capacity < nb.size())
+    return slod_fail(h, SLOD_ERR_ARGUMENT, "slod_lod_pattern: buffer too small");
+  std::copy(nb.begin(), nb.end(), neighbours);
+  return (int)nb.size();
+}
+
+static int upload_rows(slod_handle *h, const uint32_t *rows, size_t n, uint32_t **d_rows, hipStream_t st)
+{
+  for (size_t k = 0; k < n; ++k)
+    if (rows[k] >= (uint32_t)h->NP)
+      return slod_fail(h, SLOD_ERR_ARGUMENT, "row patch id out of range");
+  hipError_t e = hipMalloc((void **)d_rows, std::max<size_t>(n, 1) * sizeof(uint32_t));
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(*d_rows, rows, n * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(st); // rows is a caller-owned host array
+  return e == hipSuccess ? SLOD_OK : slod_hip_fail(h, e, "row upload");
+}
+
+int slod_lod_matrix(slod_handle *h, const uint32_t *rows, size_t n_rows, const double *d_basis, const double *d_premult,
+                    size_t stride, double *d_values, uint32_t *d_cols, void *hip_stream)
+{
+  if (!h || (n_rows && (!rows || !d_basis || !d_premult || !d_values || !d_cols)))
+    return SLOD_ERR_ARGUMENT;
+  if (n_rows == 0)
+    return SLOD_OK;
+  if (const int rc = slod_ensure_device(h))
+    return rc;
+  (void)hipSetDevice(h->cfg.device);
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->stream;
+  uint32_t   *d_rows = nullptr;
+  if (const int rc = upload_rows(h, rows, n_rows, &d_rows, st))
+    {
+      if (d_rows)
+        (void)hipFree(d_rows);
+      return rc;
+    }
+  hipLaunchKernelGGL(k_lod_matrix, dim3((unsigned)n_rows), dim3(256), 0, st, slod_grid_of(h), d_rows, d_basis, d_premult,
+                     stride, d_values, d_cols);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(st); // d_rows is freed below
+  (void)hipFree(d_rows);
+  return e == hipSuccess ? SLOD_OK : slod_hip_fail(h, e, "slod_lod_matrix");
+}
+
+int slod_lod_rhs(slod_handle *h, const uint32_t *rows, size_t n_rows, const double *d_basis, size_t stride,
+                 const double *d_fine_rhs, double *d_out, void *hip_stream)
+{
+  if (!h || (n_rows && (!rows || !d_basis || !d_fine_rhs || !d_out)))
+    return SLOD_ERR_ARGUMENT;
+  if (n_rows == 0)
+    return SLOD_OK;
+  if (const int rc = slod_ensure_device(h))
+    return rc;
+  (void)hipSetDevice(h->cfg.device);
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->stream;
+  uint32_t   *d_rows = nullptr;
+  if (const int rc = upload_rows(h, rows, n_rows, &d_rows, st))
+    {
+      if (d_rows)
+        (void)hipFree(d_rows);
+      return rc;
+    }
+  hipLaunchKernelGGL(k_lod_rhs, dim3((unsigned)n_rows), dim3(256), 0, st, slod_grid_of(h), d_rows, d_basis, stride,
+                     d_fine_rhs, d_out);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(st);
+  (void)hipFree(d_rows);
+  return e == hipSuccess ? SLOD_OK : slod_hip_fail(h, e, "slod_lod_rhs");
+}
+
+int slod_lod_solve(slod_handle *h, const double *d_values, const uint32_t *d_cols, const double *d_rhs, double *d_u,
+                   double rel_tol, int max_iterations, double *rel_residual)
+{
+  if (!h || !d_values || !d_cols || !d_rhs || !d_u || max_iterations < 0)
+    return SLOD_ERR_ARGUMENT;
+  if (const int rc = slod_ensure_device(h))
+    return rc;
+  (void)hipSetDevice(h->cfg.device);
+  hipStream_t  st = h->stream;
+  const int    s = h->cfg.spacedim, cap = slod_lod_row_capacity(h), nrow = h->NP * s;
+  const int    nblk = (nrow + 255) / 256;
+  double      *work = nullptr;
+  CgScalars   *sc = nullptr, hs;
+  hipError_t   e = hipMalloc((void **)&work, (size_t)5 * nrow * sizeof(double));
+  if (e == hipSuccess)
+    e = hipMalloc((void **)&sc, sizeof(CgScalars));
+  if (e == hipSuccess)
+    e = hipMemsetAsync(sc, 0, sizeof(CgScalars), st);
+  int it = 0;
+  if (e == hipSuccess)
+    {
+      double *r = work, *z = work + nrow, *pv = work + 2 * (size_t)nrow, *Ap = work + 3 * (size_t)nrow,
+             *dinv = work + 4 * (size_t)nrow;
+      hipLaunchKernelGGL(k_cg_init, dim3(nblk), dim3(256), 0, st, nrow, s, cap, d_values, d_cols, d_rhs, d_u, r, z, pv, dinv,
+                         sc);
+      e = hipMemcpyAsync(&hs, sc, sizeof(hs), hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess)
+        e = hipStreamSynchronize(st);
+      const double rhs2 = hs.rhs2;
+      double       rr   = hs.rr;
+      // rr of the initial residual was accumulated by k_cg_init; clear the per-iteration sums
+      if (e == hipSuccess)
+        {
+          hs.rr = 0.0;
+          hs.pAp = 0.0;
+          hs.rz_new = 0.0;
+          e = hipMemcpyAsync(sc, &hs, sizeof(hs), hipMemcpyHostToDevice, st);
+        }
+      while (e == hipSuccess && it < max_iterations && rhs2 > 0.0 && rr > rel_tol * rel_tol * rhs2)
+        {
+          // a few iterations per convergence check: the scalars stay on the device in between
+          const int burst = std::min(8, max_iterations - it);
+          for (int b = 0; b < burst; ++b)
+            {
+              hipLaunchKernelGGL(k_cg_spmv_dot, dim3(nblk), dim3(256), 0, st, nrow, s, cap, d_values, d_cols, pv, Ap, sc);
+              hipLaunchKernelGGL(k_cg_update_xr, dim3(nblk), dim3(256), 0, st, nrow, pv, Ap, dinv, d_u, r, z, sc);
+              hipLaunchKernelGGL(k_cg_update_p, dim3(nblk), dim3(256), 0, st, nrow, z, pv, sc);
+              if (b + 1 < burst)
+                hipLaunchKernelGGL(k_cg_rotate, dim3(1), dim3(1), 0, st, sc);
+            }
+          it += burst;
+          e = hipMemcpyAsync(&hs, sc, sizeof(hs), hipMemcpyDeviceToHost, st);
+          if (e == hipSuccess)
+            e = hipStreamSynchronize(st);
+          rr = hs.rr;
+          if (e == hipSuccess)
+            hipLaunchKernelGGL(k_cg_rotate, dim3(1), dim3(1), 0, st, sc);
+        }
+      if (e == hipSuccess)
+        e = hipStreamSynchronize(st);
+      if (rel_residual)
+        *rel_residual = rhs2 > 0.0 ? std::sqrt(rr / rhs2) : 0.0;
+    }
+  if (work)
+    (void)hipFree(work);
+  if (sc)
+    (void)hipFree(sc);
+  if (e != hipSuccess)
+    return slod_hip_fail(h, e, "slod_lod_solve");
+  return it;
+}
+
+int slod_lod_reconstruct(slod_handle *h, const double *d_basis, size_t stride, const double *d_u, double *d_fine,
+                         void *hip_stream)
+{
+  if (!h || !d_basis || !d_u || !d_fine)
+    return SLOD_ERR_ARGUMENT;
+  if (const int rc = slod_ensure_device(h))
+    return rc;
+  (void)hipSetDevice(h->cfg.device);
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->stream;
+  const int   NEp = h->NE + 1;
+  hipLaunchKernelGGL(k_lod_reconstruct, dim3((unsigned)((NEp * NEp + 255) / 256)), dim3(256), 0, st, slod_grid_of(h),
+                     d_basis, stride, d_u, d_fine);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SLOD_OK : slod_hip_fail(h, e, "slod_lod_reconstruct");
+}
+
+int slod_device_patch_layout(slod_handle *h, const uint32_t *patch_ids, size_t n, slod_patch_info *out)
+{
+  if (!h || (n && (!patch_ids || !out)))
+    return SLOD_ERR_ARGUMENT;
+  if (n == 0)
+    return SLOD_OK;
+  for (size_t k = 0; k < n; ++k)
+    if (patch_ids[k] >= (uint32_t)h->NP)
+      return slod_fail(h, SLOD_ERR_ARGUMENT, "slod_device_patch_layout: patch id out of range");
+  if (const int rc = slod_ensure_device(h))
+    return rc;
+  (void)hipSetDevice(h->cfg.device);
+  uint32_t        *d_ids = nullptr;
+  slod_patch_info *d_out = nullptr;
+  hipError_t       e = hipMalloc((void **)&d_ids, n * sizeof(uint32_t));
+  if (e == hipSuccess)
+    e = hipMalloc((void **)&d_out, n * sizeof(slod_patch_info));
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(d_ids, patch_ids, n * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess)
+    {
+      hipLaunchKernelGGL(k_patch_info, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, slod_grid_of(h), d_ids,
+                         (int)n, d_out);
+      e = hipGetLastError();
+    }
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(out, d_out, n * sizeof(slod_patch_info), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(h->stream);
+  if (d_ids)
+    (void)hipFree(d_ids);
+  if (d_out)
+    (void)hipFree(d_out);
+  return e == hipSuccess ? SLOD_OK : slod_hip_fail(h, e, "slod_device_patch_layout");
+}
+
+int slod_sample_coefficient(slod_handle *h, uint32_t problem, int field, const double *d_vals, int r)
+{
+  if (!h || !d_vals)
+    return SLOD_ERR_ARGUMENT;
+  if (problem >= (uint32_t)h->cfg.n_problems || field < 0 || field >= h->cfg.spacedim || r < 0 || r > 14)
+    return slod_fail(h, SLOD_ERR_ARGUMENT, "slod_sample_coefficient: problem/field/r out of range");
+  if (const int rc = slod_ensure_device(h))
+    return rc;
+  (void)hipSetDevice(h->cfg.device);
+  const size_t cnt = (size_t)h->NE * h->NE * 4;
+  hipLaunchKernelGGL(k_sample_coefficient, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, h->NE, d_vals, r,
+                     h->d_coef[field] + (size_t)problem * cnt);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(h->stream);
+  if (e != hipSuccess)
+    return slod_hip_fail(h, e, "slod_sample_coefficient");
+  h->coef_set[(size_t)problem * 2 + field] = 1;
+  return SLOD_OK;
+}
+
+} // extern "C"
+#pragma GCC visibility pop

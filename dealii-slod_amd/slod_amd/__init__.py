@@ -89,6 +89,14 @@ def load():
     lib.slod_plan_status.argtypes = [vp]
     lib.slod_plan_diagnostics.argtypes = [vp, C.POINTER(PatchDiag), C.c_size_t]
     lib.slod_compute_basis.argtypes = [vp, u32p, C.c_size_t, dp, dp, u64p]
+    lib.slod_lod_row_capacity.argtypes = [vp]
+    lib.slod_lod_pattern.argtypes = [vp, C.c_uint32, u32p, C.c_size_t]
+    lib.slod_lod_matrix.argtypes = [vp, u32p, C.c_size_t, vp, vp, C.c_size_t, vp, vp, vp]
+    lib.slod_lod_rhs.argtypes = [vp, u32p, C.c_size_t, vp, C.c_size_t, vp, vp, vp]
+    lib.slod_lod_solve.argtypes = [vp, vp, vp, vp, vp, C.c_double, C.c_int, dp]
+    lib.slod_lod_reconstruct.argtypes = [vp, vp, C.c_size_t, vp, vp, vp]
+    lib.slod_device_patch_layout.argtypes = [vp, u32p, C.c_size_t, C.POINTER(PatchInfo)]
+    lib.slod_sample_coefficient.argtypes = [vp, C.c_uint32, C.c_int, vp, C.c_int]
     lib.slod_assemble_stiffness_for_patch.argtypes = [vp, C.c_uint32, dp]
     lib.slod_patch_solution.argtypes = [vp, C.c_uint32, dp]
     _lib = lib
@@ -230,6 +238,46 @@ class Slod:
 
     def plan(self, gids, offsets=None):
         return Plan(self, gids, offsets)
+
+    # ---- consumers of (phi, psi): the global LOD system (raw device pointers as ints) ----
+    def lod_row_capacity(self):
+        return self.lib.slod_lod_row_capacity(self.h)
+
+    def lod_pattern(self, pid):
+        buf = (C.c_uint32 * self.lod_row_capacity())()
+        n = self.lib.slod_lod_pattern(self.h, pid, buf, len(buf))
+        if n < 0:
+            self._check(n)
+        return list(buf)[:n]
+
+    def lod_matrix(self, rows, d_basis, d_premult, stride, d_values, d_cols, stream=None):
+        rows = np.ascontiguousarray(rows, dtype=np.uint32)
+        self._check(self.lib.slod_lod_matrix(self.h, rows.ctypes.data_as(C.POINTER(C.c_uint32)), len(rows), d_basis,
+                                             d_premult, stride, d_values, d_cols, stream))
+
+    def lod_rhs(self, rows, d_basis, stride, d_fine_rhs, d_out, stream=None):
+        rows = np.ascontiguousarray(rows, dtype=np.uint32)
+        self._check(self.lib.slod_lod_rhs(self.h, rows.ctypes.data_as(C.POINTER(C.c_uint32)), len(rows), d_basis, stride,
+                                          d_fine_rhs, d_out, stream))
+
+    def lod_solve(self, d_values, d_cols, d_rhs, d_u, rel_tol=1e-12, max_iterations=2000):
+        res = C.c_double()
+        it = self.lib.slod_lod_solve(self.h, d_values, d_cols, d_rhs, d_u, rel_tol, max_iterations, C.byref(res))
+        if it < 0:
+            self._check(it)
+        return it, res.value
+
+    def lod_reconstruct(self, d_basis, stride, d_u, d_fine, stream=None):
+        self._check(self.lib.slod_lod_reconstruct(self.h, d_basis, stride, d_u, d_fine, stream))
+
+    def device_patch_layout(self, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        out = (PatchInfo * max(len(ids), 1))()
+        self._check(self.lib.slod_device_patch_layout(self.h, ids.ctypes.data_as(C.POINTER(C.c_uint32)), len(ids), out))
+        return [out[i] for i in range(len(ids))]
+
+    def sample_coefficient(self, field, d_vals, r, problem=0):
+        self._check(self.lib.slod_sample_coefficient(self.h, problem, field, d_vals, r))
 
     def compute_basis(self, gids, offsets=None, total=None):
         """Host-buffer path (slod_compute_basis). Returns (basis, premult) flat arrays."""

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SLOD_ABI_VERSION 2
+#define SLOD_ABI_VERSION 3
 
 typedef enum
 {
@@ -160,6 +160,56 @@ int slod_plan_diagnostics(slod_plan *p, slod_patch_diag *out, size_t capacity);
  * calls).  basis/premult are HOST pointers. */
 int slod_compute_basis(slod_handle *h, const uint32_t *gids, size_t n, double *basis,
                        double *premult, const uint64_t *offsets);
+
+/* ---- consumers of (phi, psi): the global LOD system ----------------------------------
+ * Reference: assemble_global_matrix (LOD.cc:860-973), solve (LOD.cc:976-1002), and the
+ * fine-scale reconstruction  solution_fine = C u_H  (LOD.cc:1251).  All vectors of ONE problem
+ * sit in a slab with uniform stride (slod_plan_stride(): what a plan with NULL offsets
+ * writes and what the all-gather of the multi-GPU path produces): patch p at
+ * d_basis[p * stride + d * n_fine(p) + dof].  Overlaps of patches are index arithmetic on
+ * the patch-lexicographic layout; no deal.II numbering is involved. */
+/* Upper bound of patches q whose node set meets that of one patch: (4 l + 1)^2. */
+int slod_lod_row_capacity(const slod_handle *h);
+/* Patches coupled with `patch_id` in A_LOD (LOD.cc:970-971 pattern of Tmmult), ascending ids;
+ * returns their count.  HOST buffer. */
+int slod_lod_pattern(const slod_handle *h, uint32_t patch_id, uint32_t *neighbours, size_t capacity);
+/* Block rows of  A_LOD = C^T (A C)  (basis_matrix_transposed.Tmmult(global_stiffness_matrix,
+ * premultiplied_basis_matrix), LOD.cc:970-971) for the patches rows[0..n_rows):
+ *   d_values[(k * cap + j) * s * s + d * s + e] = sum_i phi_{rows[k],d}(i) psi_{q,e}(i),
+ *   q = d_cols[k * cap + j]  (0xffffffff = unused slot), cap = slod_lod_row_capacity().
+ * Column (q,e) of the reference matrix is spacedim * q + e (LOD.cc:942-944).  rows is a HOST
+ * array; d_* are DEVICE pointers; asynchronous on hip_stream. */
+int slod_lod_matrix(slod_handle *h, const uint32_t *rows, size_t n_rows, const double *d_basis,
+                    const double *d_premult, size_t stride, double *d_values, uint32_t *d_cols,
+                    void *hip_stream);
+/* system_rhs = C^T fem_rhs (basis_matrix_transposed.Tvmult, LOD.cc:982): d_out[k * s + d] =
+ * sum_i phi_{rows[k],d}(i) f(i); d_fine_rhs is the fine FEM load vector on the GLOBAL fine
+ * grid, [(NE+1)^2][s] lexicographic, component-minor. */
+int slod_lod_rhs(slod_handle *h, const uint32_t *rows, size_t n_rows, const double *d_basis, size_t stride,
+                 const double *d_fine_rhs, double *d_out, void *hip_stream);
+/* Solves A_LOD u = rhs for all num_patches * s unknowns (the reference: CG + SSOR(1.2),
+ * LOD.cc:990-998; here Jacobi-preconditioned CG, all on the device) from the block rows of
+ * slod_lod_matrix for rows = 0 .. num_patches-1.  Returns the iteration count (>= 0) or a
+ * negative slod_status; *rel_residual (HOST, may be NULL) receives ||r|| / ||rhs||.  Synchronises. */
+int slod_lod_solve(slod_handle *h, const double *d_values, const uint32_t *d_cols, const double *d_rhs,
+                   double *d_u, double rel_tol, int max_iterations, double *rel_residual);
+/* solution_fine = C u_H (LOD.cc:1251: basis_matrix_transposed.vmult): d_fine[(ix + iy (NE+1)) s + c]
+ * = sum over patches covering the node, sum_d phi_{p,d}(node, c) u[p s + d]. */
+int slod_lod_reconstruct(slod_handle *h, const double *d_basis, size_t stride, const double *d_u,
+                         double *d_fine, void *hip_stream);
+
+/* ---- inputs of the path produced on the device --------------------------------------
+ * create_patches + create_mesh_for_patch + fill_dofs_indices_vector (LOD.cc:122-244,
+ * 770-858; LODtools.h:334-375) evaluated by a kernel, one thread per patch; out is a HOST
+ * array of n entries, equal to slod_patch_layout() entry by entry (tests check both against
+ * the reference golden tests/create_patch_01.output). */
+int slod_device_patch_layout(slod_handle *h, const uint32_t *patch_ids, size_t n, slod_patch_info *out);
+/* The reference's coefficient object problem_parameter(min, max, r) (Diffusion.h:7-54): a
+ * piecewise constant on a 2^r x 2^r grid, value(p) = vals[floor(x / eta) + 2^r floor(y / eta)],
+ * eta = 2^-r (:47-51), sampled ON THE DEVICE at the points of quadrature_fine of every fine
+ * element (what Alpha.value_list does at Diffusion.h:154).  d_vals: DEVICE, 4^r values in
+ * the reference's fill order (:30-36). */
+int slod_sample_coefficient(slod_handle *h, uint32_t problem, int field, const double *d_vals, int r);
 
 /* ---- pieces exposed for parity tests ----------------------------------------------- */
 /* unconstrained patch stiffness (replaces assemble_stiffness with empty constraints,

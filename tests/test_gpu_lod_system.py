@@ -1,0 +1,217 @@
+"""GPU tests of the rows SURVEY 8(f) marks "next": the global LOD system built from (phi, psi) --
+A_LOD = C^T (A C) and C^T f (reference assemble_global_matrix LOD.cc:860-973, solve LOD.cc:976-1002),
+its solve, the fine-scale reconstruction (LOD.cc:1251) -- and the inputs of the path produced on
+the device (patch descriptors, coefficient sampling).  Reference-held numbers used:
+  tests/parallel_assembly.output   all-ones basis, 32 x 32 A_LOD, exact integers
+  tests/Poisson_LOD_Example.output  "fem rhs l2 norm = 0.109375" (exact), "rhs l2 norm = 0.0808367"
+                                    (depends on the unseeded rand() stream: statistical, ~1e-2)
+  tests/create_patch_01.output      patch sizes in Morton order
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, make_fields
+from test_gpu_parity import _mk, _upload
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    return torch, torch.device("cuda", 0)
+
+
+def _global_dense(g, cfg_s, basis, premult, stride):
+    """Scatter every patch vector to the global fine grid: (N_patches*s) x (NEp^2 * s) dense arrays."""
+    s, n, NP = cfg_s, g.cfg.n_subdivisions, g.num_patches
+    NEp = g.NE + 1
+    Phi = np.zeros((NP * s, NEp * NEp * s))
+    Psi = np.zeros_like(Phi)
+    for p in range(NP):
+        info = g.patch_layout(p)
+        nxp, nyp = info.nx + 1, info.ny + 1
+        for d in range(s):
+            vphi = basis[p * stride + d * info.n_fine:p * stride + (d + 1) * info.n_fine].reshape(nyp, nxp, s)
+            vpsi = premult[p * stride + d * info.n_fine:p * stride + (d + 1) * info.n_fine].reshape(nyp, nxp, s)
+            G1 = Phi[p * s + d].reshape(NEp, NEp, s)
+            G2 = Psi[p * s + d].reshape(NEp, NEp, s)
+            G1[info.y0 * n:info.y0 * n + nyp, info.x0 * n:info.x0 * n + nxp, :] = vphi
+            G2[info.y0 * n:info.y0 * n + nyp, info.x0 * n:info.x0 * n + nxp, :] = vpsi
+    return Phi, Psi
+
+
+def _rows_to_dense(g, values, cols, s):
+    NP, cap = g.num_patches, g.lod_row_capacity()
+    A = np.zeros((NP * s, NP * s))
+    v = values.reshape(NP, cap, s, s)
+    c = cols.reshape(NP, cap)
+    for p in range(NP):
+        for j in range(cap):
+            if c[p, j] != 0xffffffff:
+                q = int(c[p, j])
+                A[p * s:(p + 1) * s, q * s:(q + 1) * s] = v[p, j]
+    return A
+
+
+def _lod_matrix(g, basis_t, premult_t, stride, s):
+    torch, dev = _torch()
+    NP, cap = g.num_patches, g.lod_row_capacity()
+    values = torch.zeros(NP * cap * s * s, dtype=torch.float64, device=dev)
+    cols = torch.zeros(NP * cap, dtype=torch.int32, device=dev)
+    g.lod_matrix(np.arange(NP), basis_t.data_ptr(), premult_t.data_ptr(), stride, values.data_ptr(), cols.data_ptr())
+    torch.cuda.synchronize()
+    return values, cols
+
+
+def test_parallel_assembly_golden(so):
+    """tests/parallel_assembly.cc: H=1/4, n=2, l=1, LOD<2,2>, every basis function == 1 on its patch
+    (premultiplied too): A_LOD[(p,d),(q,e)] = 2 * #shared fine nodes.  The 1024 printed entries
+    come out of the HIP kernel exactly."""
+    torch, dev = _torch()
+    cfg, g = _mk(so, nref=2, n_sub=2, oversampling=1, spacedim=2, stabilize=1)
+    s = 2
+    plan = g.plan(np.arange(g.num_patches, dtype=np.uint32))   # only for the slab stride
+    stride = plan.stride
+    hb = np.zeros(g.num_patches * stride)
+    for p in range(g.num_patches):
+        info = g.patch_layout(p)
+        hb[p * stride:p * stride + s * info.n_fine] = 1.0
+    b = torch.from_numpy(hb).to(dev)
+    values, cols = _lod_matrix(g, b, b, stride, s)
+    A = _rows_to_dense(g, values.cpu().numpy(), cols.cpu().numpy().view(np.uint32), s)
+    lines = open(os.path.join(GOLDEN, "reference", "parallel_assembly.output")).read().split("\n")
+    n = 0
+    for ln in lines:
+        if not ln.startswith("("):
+            continue
+        ij, val = ln.split(")")
+        i, j = (int(x) for x in ij[1:].split(","))
+        assert A[i, j] == float(val), (i, j, A[i, j], val)
+        n += 1
+    assert n == 1024
+    # the pattern entry point agrees with the kernel's columns
+    c = cols.cpu().numpy().view(np.uint32).reshape(g.num_patches, -1)
+    for p in range(g.num_patches):
+        assert sorted(int(x) for x in c[p] if x != 0xffffffff) == g.lod_pattern(p)
+
+
+@pytest.mark.parametrize("kw", [dict(nref=3, n_sub=4, oversampling=1, spacedim=1),
+                                dict(nref=3, n_sub=2, oversampling=2, spacedim=1),
+                                dict(nref=2, n_sub=4, oversampling=1, spacedim=2)])
+def test_lod_system_matches_dense_numpy(so, kw):
+    """A_LOD, C^T f, the coarse solve and the reconstruction from the HIP kernels against dense
+    numpy on the same (phi, psi): A = Phi Psi^T over the global fine grid, u = A^-1 C^T f,
+    u_fine = Phi^T u."""
+    torch, dev = _torch()
+    cfg, g = _mk(so, stabilize=1, **kw)
+    s = kw["spacedim"]
+    fields = make_fields(so, cfg, "D100")
+    _upload(g, fields)
+    ids = np.arange(g.num_patches, dtype=np.uint32)
+    plan = g.plan(ids)
+    stride = plan.stride
+    b = torch.zeros(len(ids) * stride, dtype=torch.float64, device=dev)
+    q = torch.zeros_like(b)
+    plan.execute(b.data_ptr(), q.data_ptr())
+    plan.status()
+    values, cols = _lod_matrix(g, b, q, stride, s)
+    A = _rows_to_dense(g, values.cpu().numpy(), cols.cpu().numpy().view(np.uint32), s)
+    Phi, Psi = _global_dense(g, s, b.cpu().numpy(), q.cpu().numpy(), stride)
+    Aref = Phi @ Psi.T
+    scale = np.abs(Aref).max()
+    assert np.abs(A - Aref).max() <= 1e-12 * scale
+    assert np.abs(A - A.T).max() <= 1e-9 * scale          # A_LOD is symmetric up to the basis accuracy
+    # rhs: f = 1 lumped on the interior fine nodes (the "fem rhs" of Poisson_LOD_Example for f == 1)
+    NEp = g.NE + 1
+    hfine = 1.0 / g.NE
+    f = np.zeros((NEp, NEp, s))
+    f[1:-1, 1:-1, :] = hfine * hfine
+    ft = torch.from_numpy(f.ravel()).to(dev)
+    rhs = torch.zeros(g.num_patches * s, dtype=torch.float64, device=dev)
+    g.lod_rhs(ids, b.data_ptr(), stride, ft.data_ptr(), rhs.data_ptr())
+    torch.cuda.synchronize()
+    rref = Phi @ f.ravel()
+    assert np.abs(rhs.cpu().numpy() - rref).max() <= 1e-13 * np.abs(rref).max()
+    # coarse solve (Jacobi-CG on the device) vs a dense solve, then u_fine = C u_H
+    u = torch.zeros_like(rhs)
+    it, res = g.lod_solve(values.data_ptr(), cols.data_ptr(), rhs.data_ptr(), u.data_ptr(), 1e-13, 5000)
+    uref = np.linalg.solve(0.5 * (Aref + Aref.T), rref)
+    assert res <= 1e-12 and it > 0
+    assert np.abs(u.cpu().numpy() - uref).max() <= 1e-8 * np.abs(uref).max()
+    fine = torch.zeros(NEp * NEp * s, dtype=torch.float64, device=dev)
+    g.lod_reconstruct(b.data_ptr(), stride, u.data_ptr(), fine.data_ptr())
+    torch.cuda.synchronize()
+    fref = Phi.T @ u.cpu().numpy()
+    assert np.abs(fine.cpu().numpy() - fref).max() <= 1e-12 * np.abs(fref).max()
+
+
+def test_poisson_lod_example_rhs_norm(so):
+    """tests/Poisson_LOD_Example.output: H=1/4, n=2, l=1, plain LOD, constant_coefficients (matrix
+    re-use quirk) with a rand() field Alpha(1,100,8), f == 1.  'fem rhs l2 norm = 0.109375' is exact;
+    'rhs l2 norm = 0.0808367' depends on the unseeded rand() stream at capture time: the whole HIP
+    chain (assemble, solve, LOD selection, normalise, C^T f) reproduces it to the 1e-2 level the
+    golden can pin (seeds give 0.0803 .. 0.0811)."""
+    torch, dev = _torch()
+    cfg, g = _mk(so, nref=2, n_sub=2, oversampling=1, stabilize=0, reuse_full=1)
+    field = so.fill_coefficient_rand(1.0, 100.0, 8, g.NE, seed=1)
+    g.set_coefficient(0, field)
+    ids = np.arange(g.num_patches, dtype=np.uint32)
+    plan = g.plan(ids)
+    b = torch.zeros(len(ids) * plan.stride, dtype=torch.float64, device=dev)
+    q = torch.zeros_like(b)
+    plan.execute(b.data_ptr(), q.data_ptr())
+    plan.status()
+    NEp = g.NE + 1
+    f = np.zeros((NEp, NEp))
+    f[1:-1, 1:-1] = (1.0 / g.NE) ** 2
+    assert abs(np.linalg.norm(f) - 0.109375) < 1e-15
+    ft = torch.from_numpy(f.ravel()).to(dev)
+    rhs = torch.zeros(g.num_patches, dtype=torch.float64, device=dev)
+    g.lod_rhs(ids, b.data_ptr(), plan.stride, ft.data_ptr(), rhs.data_ptr())
+    torch.cuda.synchronize()
+    nrm = float(torch.linalg.norm(rhs))
+    assert abs(nrm - 0.0808367) < 1e-3, nrm
+
+
+def test_device_patch_layout_matches_host_and_golden():
+    """Patch descriptors from the device kernel == the host index calculus, and both reproduce
+    tests/create_patch_01.output (32 x 32 cells, oversampling 4, Morton order)."""
+    import slod_amd
+    g = slod_amd.Slod(nref=5, n_sub=1, oversampling=4)
+    ids = np.arange(g.num_patches, dtype=np.uint32)
+    dev_infos = g.device_patch_layout(ids)
+    lines = open(os.path.join(GOLDEN, "reference", "create_patch_01.output")).read().strip().split("\n")[1:]
+    for ln in lines:
+        pid = int(ln.split(":")[0][2:])
+        cnt = int(ln.split("{")[1].split("}")[0])
+        assert dev_infos[pid].mx * dev_infos[pid].my == cnt
+    for kw in (dict(nref=3, n_sub=4, oversampling=2, spacedim=2), dict(n_cells=6, n_sub=3, oversampling=1), dict(nref=2, n_sub=2, oversampling=2, stabilize=0)):
+        g = slod_amd.Slod(**kw)
+        ids = np.arange(g.num_patches, dtype=np.uint32)
+        for pid, di in zip(ids, g.device_patch_layout(ids)):
+            hi = g.patch_layout(int(pid))
+            assert bytes(di) == bytes(hi), (kw, pid)
+
+
+def test_device_coefficient_sampling_matches_reference_formula(so):
+    """problem_parameter::value (Diffusion.h:40-53) sampled on the device at the points of
+    quadrature_fine == the oracle's host evaluation of the same glibc rand() field, bit for bit;
+    the basis built from it equals the basis built from the uploaded host field."""
+    torch, dev = _torch()
+    cfg, g = _mk(so, nref=3, n_sub=4, oversampling=1, stabilize=1)
+    r, lo, hi = 4, 1.0, 100.0
+    libc = C.CDLL("libc.so.6")
+    libc.srand(7)
+    f32 = np.float32
+    vals = np.array([lo + float(f32(libc.rand()) / f32(f32(2147483647) / f32(hi - lo))) for _ in range(4 ** r)])
+    field = so.fill_coefficient_rand(lo, hi, r, g.NE, seed=7)
+    vt = torch.from_numpy(vals).to(dev)
+    g.sample_coefficient(0, vt.data_ptr(), r)
+    ids = np.arange(g.num_patches, dtype=np.uint32)
+    b1, p1, _ = g.compute_basis(ids)
+    g.set_coefficient(0, field)
+    b0, p0, _ = g.compute_basis(ids)
+    assert np.array_equal(b0, b1) and np.array_equal(p0, p1)
