@@ -256,6 +256,32 @@ namespace
   }
 } // namespace
 
+namespace
+{
+  // the launches of the patches [first, first + cnt) of a plan (cnt <= chunk: one workspace slot per
+  // workgroup); ev (optional): four events around the three stages
+  hipError_t launch_range(slod_plan *p, size_t first, int cnt, double *d_basis, double *d_premult, hipStream_t st,
+                          hipEvent_t *ev)
+  {
+    const int      s = p->h->cfg.spacedim;
+    SlodKernelArgs a = make_args(p, first, d_basis, d_premult);
+    hipError_t     e = ev ? hipEventRecord(ev[0], st) : hipSuccess;
+    if (e == hipSuccess && !p->choice.fuse_assemble)
+      e = slod_launch_assemble(s, a, cnt, st);
+    if (e == hipSuccess && ev)
+      e = hipEventRecord(ev[1], st);
+    if (e == hipSuccess)
+      e = slod_launch_solve(s, p->choice, a, cnt, st); // sets a.m_fused, a.fuse_select, a.fuse_assemble
+    if (e == hipSuccess && ev)
+      e = hipEventRecord(ev[2], st);
+    if (e == hipSuccess && !a.fuse_select)
+      e = slod_launch_select(s, a, cnt, p->nb_buf, p->nf_max, st);
+    if (e == hipSuccess && ev)
+      e = hipEventRecord(ev[3], st);
+    return e;
+  }
+} // namespace
+
 #pragma GCC visibility push(default)
 extern "C" {
 
@@ -613,25 +639,10 @@ int slod_plan_execute(slod_plan *p, double *d_basis, double *d_premult, void *hi
   const int   s  = h->cfg.spacedim;
   hipError_t  e  = hipMemsetAsync(p->d_status, 0, sizeof(int32_t), st);
   size_t      ci = 0;
+  (void)s;
   for (size_t first = 0; first < p->n && e == hipSuccess; first += p->chunk, ++ci)
-    {
-      const int            cnt = (int)std::min(p->chunk, p->n - first);
-      SlodKernelArgs       a   = make_args(p, first, d_basis, d_premult);
-      hipEvent_t          *ev  = &p->ev[4 * ((p->n_exec % (size_t)p->depth) * p->n_chunks + ci)];
-      e = hipEventRecord(ev[0], st);
-      if (e == hipSuccess && !p->choice.fuse_assemble)
-        e = slod_launch_assemble(s, a, cnt, st);
-      if (e == hipSuccess)
-        e = hipEventRecord(ev[1], st);
-      if (e == hipSuccess)
-        e = slod_launch_solve(s, p->choice, a, cnt, st); // sets a.m_fused, a.fuse_select, a.fuse_assemble
-      if (e == hipSuccess)
-        e = hipEventRecord(ev[2], st);
-      if (e == hipSuccess && !a.fuse_select)
-        e = slod_launch_select(s, a, cnt, p->nb_buf, p->nf_max, st);
-      if (e == hipSuccess)
-        e = hipEventRecord(ev[3], st);
-    }
+    e = launch_range(p, first, (int)std::min(p->chunk, p->n - first), d_basis, d_premult, st,
+                     &p->ev[4 * ((p->n_exec % (size_t)p->depth) * p->n_chunks + ci)]);
   if (e != hipSuccess)
     return hip_fail(h, e, "slod_plan_execute");
   p->ran = true;
@@ -888,6 +899,237 @@ int slod_patch_solution(slod_handle *h, uint32_t gid, double *X)
     (void)hipFree(dp);
   slod_plan_destroy(p);
   return rc;
+}
+
+} // extern "C"
+
+// ---- multi-GPU exchange for a C/C++ host: RCCL, resolved at run time -------------------
+// librccl is dlopen'ed on first use (RTLD_NOLOAD first: a process that already runs RCCL --
+// PyTorch ships its own copy -- must not get a second one); the library has no link-time
+// dependency on it and single-GPU users never load it.
+#include <dlfcn.h>
+
+namespace
+{
+  struct Rccl
+  {
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *)                                                             = nullptr;
+    int (*CommInitRank)(void **, int, slod_comm_id, int)                                   = nullptr;
+    int (*CommDestroy)(void *)                                                             = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t)               = nullptr;
+    int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t)          = nullptr;
+    int (*GroupStart)()                                                                    = nullptr;
+    int (*GroupEnd)()                                                                      = nullptr;
+    const char *(*GetErrorString)(int)                                                     = nullptr;
+    std::string error;
+  };
+  Rccl &rccl()
+  {
+    static Rccl r;
+    if (r.lib || !r.error.empty())
+      return r;
+    const char *names[] = {"librccl.so", "librccl.so.1"};
+    for (const char *n : names)
+      if (!r.lib)
+        r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+    for (const char *n : names)
+      if (!r.lib)
+        r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!r.lib)
+      {
+        r.error = std::string("librccl not found: ") + dlerror();
+        return r;
+      }
+    auto sym = [&](const char *n) {
+      void *f = dlsym(r.lib, n);
+      if (!f && r.error.empty())
+        r.error = std::string("librccl lacks ") + n;
+      return f;
+    };
+    r.GetUniqueId    = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+    r.CommInitRank   = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+    r.CommDestroy    = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.AllGather      = (decltype(r.AllGather))sym("ncclAllGather");
+    r.Broadcast      = (decltype(r.Broadcast))sym("ncclBroadcast");
+    r.GroupStart     = (decltype(r.GroupStart))sym("ncclGroupStart");
+    r.GroupEnd       = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+    r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    return r;
+  }
+  constexpr int kNcclFloat64 = 8; // rccl.h: ncclFloat64 = ncclDouble = 8
+} // namespace
+
+struct slod_comm
+{
+  void       *nccl = nullptr;
+  int         n_ranks = 1, rank = 0, device = 0;
+  std::string error;
+};
+
+namespace
+{
+  thread_local std::string g_comm_error;
+  int comm_fail(slod_comm *c, int code, const std::string &msg)
+  {
+    (c ? c->error : g_comm_error) = msg;
+    return code;
+  }
+  int nccl_fail(slod_comm *c, int rc, const char *what)
+  {
+    return comm_fail(c, SLOD_ERR_DEVICE, std::string(what) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(rc) : "?"));
+  }
+} // namespace
+
+extern "C" {
+
+const char *slod_comm_last_error(const slod_comm *c) { return c ? c->error.c_str() : g_comm_error.c_str(); }
+
+int slod_comm_unique_id(slod_comm_id *id)
+{
+  if (!id)
+    return SLOD_ERR_ARGUMENT;
+  Rccl &r = rccl();
+  if (!r.error.empty())
+    return comm_fail(nullptr, SLOD_ERR_DEVICE, r.error);
+  const int rc = r.GetUniqueId(id);
+  return rc ? nccl_fail(nullptr, rc, "ncclGetUniqueId") : SLOD_OK;
+}
+
+int slod_comm_create(const slod_comm_id *id, int n_ranks, int rank, int device, slod_comm **out)
+{
+  if (!id || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks)
+    return SLOD_ERR_ARGUMENT;
+  *out    = nullptr;
+  Rccl &r = rccl();
+  if (!r.error.empty())
+    return comm_fail(nullptr, SLOD_ERR_DEVICE, r.error);
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess)
+    return comm_fail(nullptr, SLOD_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+  slod_comm *c = new slod_comm;
+  c->n_ranks   = n_ranks;
+  c->rank      = rank;
+  c->device    = device;
+  const int rc = r.CommInitRank(&c->nccl, n_ranks, *id, rank);
+  if (rc)
+    {
+      const int code = nccl_fail(nullptr, rc, "ncclCommInitRank");
+      delete c;
+      return code;
+    }
+  *out = c;
+  return SLOD_OK;
+}
+
+void slod_comm_destroy(slod_comm *c)
+{
+  if (!c)
+    return;
+  if (c->nccl && rccl().CommDestroy)
+    (void)rccl().CommDestroy(c->nccl);
+  delete c;
+}
+
+int slod_comm_allgather(slod_comm *c, const double *d_send, double *d_recv, size_t count, void *hip_stream)
+{
+  if (!c || !d_send || !d_recv)
+    return SLOD_ERR_ARGUMENT;
+  const int rc = rccl().AllGather(d_send, d_recv, count, kNcclFloat64, c->nccl, (hipStream_t)hip_stream);
+  return rc ? nccl_fail(c, rc, "ncclAllGather") : SLOD_OK;
+}
+
+int slod_gather_piece(uint64_t patches_per_rank, uint32_t n_pieces, uint32_t piece, uint64_t *first, uint64_t *count)
+{
+  if (!first || !count || n_pieces == 0 || piece >= n_pieces)
+    return SLOD_ERR_ARGUMENT;
+  const uint64_t pp = (patches_per_rank + n_pieces - 1) / n_pieces;
+  *first            = std::min<uint64_t>((uint64_t)piece * pp, patches_per_rank);
+  *count            = std::min<uint64_t>(pp, patches_per_rank - *first);
+  return SLOD_OK;
+}
+
+int slod_plan_execute_allgather(slod_plan *p, slod_comm *c, double *d_basis_all, double *d_premult_all,
+                                size_t patches_per_rank, int n_pieces, void *compute_stream, void *comm_stream)
+{
+  if (!p || !c || n_pieces < 1)
+    return SLOD_ERR_ARGUMENT;
+  slod_handle *h = p->h;
+  if (!d_basis_all || !d_premult_all || !compute_stream || !comm_stream || compute_stream == comm_stream)
+    return fail(h, SLOD_ERR_ARGUMENT, "slod_plan_execute_allgather: needs two distinct streams and both slabs");
+  if (p->n > patches_per_rank)
+    return fail(h, SLOD_ERR_ARGUMENT, "slod_plan_execute_allgather: plan larger than a rank's slab");
+  for (size_t k = 0; k < p->n; ++k)
+    {
+      if (p->desc[k].out_off != (uint64_t)k * p->stride)
+        return fail(h, SLOD_ERR_STATE, "slod_plan_execute_allgather: the plan must use the uniform stride (NULL offsets)");
+      for (int f = 0; f < h->cfg.spacedim; ++f)
+        if (!h->coef_set[(size_t)p->desc[k].prob * 2 + f])
+          return fail(h, SLOD_ERR_STATE, "slod_plan_execute_allgather: coefficient field not set");
+    }
+  (void)hipSetDevice(h->cfg.device);
+  hipStream_t  cs = (hipStream_t)compute_stream, ns = (hipStream_t)comm_stream;
+  const size_t slab = patches_per_rank * p->stride;
+  double      *mb = d_basis_all + (size_t)c->rank * slab, *mp = d_premult_all + (size_t)c->rank * slab;
+  hipError_t   e  = p->n ? hipMemsetAsync(p->d_status, 0, sizeof(int32_t), cs) : hipSuccess;
+  Rccl        &r  = rccl();
+  for (int piece = 0; piece < n_pieces && e == hipSuccess; ++piece)
+    {
+      uint64_t first, count;
+      (void)slod_gather_piece(patches_per_rank, (uint32_t)n_pieces, (uint32_t)piece, &first, &count);
+      if (count == 0)
+        break;
+      // this rank's patches of the piece (the padded tail of a rank with fewer patches stays as it is)
+      const size_t mine = first < p->n ? std::min<size_t>(count, p->n - first) : 0;
+      for (size_t k = 0; k < mine && e == hipSuccess; k += p->chunk)
+        e = launch_range(p, first + k, (int)std::min(p->chunk, mine - k), mb, mp, cs, nullptr);
+      // the exchange of piece i overlaps the computation of piece i + 1: the communication stream
+      // waits for the piece only
+      hipEvent_t ev = nullptr;
+      if (e == hipSuccess)
+        e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+      if (e == hipSuccess)
+        e = hipEventRecord(ev, cs);
+      if (e == hipSuccess)
+        e = hipStreamWaitEvent(ns, ev, 0);
+      if (ev)
+        (void)hipEventDestroy(ev); // released when the recorded work has completed
+      if (e != hipSuccess)
+        break;
+      // every rank's piece to every rank, in place: one broadcast per root and array, grouped
+      // (the pieces of different ranks are not contiguous in the gathered slab, so this is not
+      // an ncclAllGather; xGMI is point to point: the group drives all links at once)
+      int rc = r.GroupStart();
+      for (int root = 0; root < c->n_ranks && !rc; ++root)
+        {
+          double *pb = d_basis_all + (size_t)root * slab + first * p->stride;
+          double *pq = d_premult_all + (size_t)root * slab + first * p->stride;
+          rc         = r.Broadcast(pb, pb, count * p->stride, kNcclFloat64, root, c->nccl, ns);
+          if (!rc)
+            rc = r.Broadcast(pq, pq, count * p->stride, kNcclFloat64, root, c->nccl, ns);
+        }
+      const int rc2 = r.GroupEnd();
+      if (rc || rc2)
+        return nccl_fail(c, rc ? rc : rc2, "ncclBroadcast (grouped)"), fail(h, SLOD_ERR_DEVICE, c->error);
+    }
+  // later work on the compute stream sees the gathered slabs
+  hipEvent_t done = nullptr;
+  if (e == hipSuccess)
+    e = hipEventCreateWithFlags(&done, hipEventDisableTiming);
+  if (e == hipSuccess)
+    e = hipEventRecord(done, ns);
+  if (e == hipSuccess)
+    e = hipStreamWaitEvent(cs, done, 0);
+  if (done)
+    (void)hipEventDestroy(done);
+  if (e != hipSuccess)
+    return hip_fail(h, e, "slod_plan_execute_allgather");
+  if (p->n)
+    {
+      p->ran = true;
+      ++p->n_exec;
+    }
+  return SLOD_OK;
 }
 
 } // extern "C"

@@ -89,6 +89,15 @@ def load():
     lib.slod_plan_status.argtypes = [vp]
     lib.slod_plan_diagnostics.argtypes = [vp, C.POINTER(PatchDiag), C.c_size_t]
     lib.slod_compute_basis.argtypes = [vp, u32p, C.c_size_t, dp, dp, u64p]
+    lib.slod_comm_last_error.restype = C.c_char_p
+    lib.slod_comm_last_error.argtypes = [vp]
+    lib.slod_comm_unique_id.argtypes = [C.c_char_p]
+    lib.slod_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.slod_comm_destroy.argtypes = [vp]
+    lib.slod_comm_destroy.restype = None
+    lib.slod_comm_allgather.argtypes = [vp, vp, vp, C.c_size_t, vp]
+    lib.slod_gather_piece.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, u64p, u64p]
+    lib.slod_plan_execute_allgather.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_int, vp, vp]
     lib.slod_lod_row_capacity.argtypes = [vp]
     lib.slod_lod_pattern.argtypes = [vp, C.c_uint32, u32p, C.c_size_t]
     lib.slod_lod_matrix.argtypes = [vp, u32p, C.c_size_t, vp, vp, C.c_size_t, vp, vp, vp]
@@ -122,6 +131,45 @@ def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
+def gather_piece(patches_per_rank, n_pieces, piece):
+    f, c = C.c_uint64(), C.c_uint64()
+    rc = load().slod_gather_piece(patches_per_rank, n_pieces, piece, C.byref(f), C.byref(c))
+    if rc:
+        raise SlodError(rc, "slod_gather_piece: bad arguments")
+    return f.value, c.value
+
+
+class Comm:
+    """slod_comm: RCCL communicator of the C-ABI (what a C++ host uses; bench.py's N > 1 path goes
+    through torch.distributed instead)."""
+
+    def __init__(self, comm_id, n_ranks, rank, device=0):
+        self.lib = load()
+        self.c = C.c_void_p()
+        rc = self.lib.slod_comm_create(comm_id, n_ranks, rank, device, C.byref(self.c))
+        if rc:
+            raise SlodError(rc, self.lib.slod_comm_last_error(None).decode())
+        self.n_ranks, self.rank = n_ranks, rank
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        rc = load().slod_comm_unique_id(buf)
+        if rc:
+            raise SlodError(rc, load().slod_comm_last_error(None).decode())
+        return buf.raw
+
+    def allgather(self, d_send, d_recv, count, stream):
+        rc = self.lib.slod_comm_allgather(self.c, d_send, d_recv, count, stream)
+        if rc:
+            raise SlodError(rc, self.lib.slod_comm_last_error(self.c).decode())
+
+    def close(self):
+        if self.c:
+            self.lib.slod_comm_destroy(self.c)
+            self.c = None
+
+
 class Plan:
     def __init__(self, slod, gids, offsets=None):
         self.slod = slod
@@ -141,6 +189,11 @@ class Plan:
     def execute(self, d_basis_ptr, d_premult_ptr, stream_ptr=None):
         """Asynchronous launch; arguments are raw device pointers (ints)."""
         self.slod._check(self.lib.slod_plan_execute(self.p, d_basis_ptr, d_premult_ptr, stream_ptr))
+
+    def execute_allgather(self, comm, d_basis_all, d_premult_all, patches_per_rank, n_pieces, compute_stream,
+                          comm_stream):
+        self.slod._check(self.lib.slod_plan_execute_allgather(self.p, comm.c, d_basis_all, d_premult_all,
+                                                              patches_per_rank, n_pieces, compute_stream, comm_stream))
 
     def profile(self, depth):
         self.slod._check(self.lib.slod_plan_profile(self.p, depth))

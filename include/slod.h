@@ -211,6 +211,37 @@ int slod_device_patch_layout(slod_handle *h, const uint32_t *patch_ids, size_t n
  * the reference's fill order (:30-36). */
 int slod_sample_coefficient(slod_handle *h, uint32_t problem, int field, const double *d_vals, int r);
 
+/* ---- multi-GPU exchange (north_star: RCCL all-gather over xGMI of the basis vectors) ----
+ * The reference never communicates basis vectors (its MPI path is unfinished, LOD.cc:225-229,
+ * 895-897); the split it prescribes is contiguous blocks of patch ids per rank (LOD.cc:116-118,
+ * slod_partition).  One process per GPU; the C/C++ host exchanges the 128-byte id out of band
+ * (MPI_Bcast in dealii-slod) and then needs nothing but this library: RCCL is resolved at run
+ * time (no link-time dependency; a process that already runs RCCL re-uses that copy). */
+typedef struct
+{
+  char internal[128]; /* ncclUniqueId */
+} slod_comm_id;
+typedef struct slod_comm slod_comm;
+const char *slod_comm_last_error(const slod_comm *c); /* c may be NULL: last failed create */
+int         slod_comm_unique_id(slod_comm_id *id);    /* on rank 0; ship it to the other ranks */
+int         slod_comm_create(const slod_comm_id *id, int n_ranks, int rank, int device, slod_comm **out);
+void        slod_comm_destroy(slod_comm *c);
+/* plain ncclAllGather of `count` doubles per rank on hip_stream (uniform-stride slabs) */
+int slod_comm_allgather(slod_comm *c, const double *d_send, double *d_recv, size_t count, void *hip_stream);
+/* Patch range [first, first + count) of piece `piece` out of n_pieces of a rank's padded slab of
+ * patches_per_rank patches (host-only index calculus of slod_plan_execute_allgather). */
+int slod_gather_piece(uint64_t patches_per_rank, uint32_t n_pieces, uint32_t piece, uint64_t *first,
+                      uint64_t *count);
+/* Basis construction of this rank's patches and their exchange, overlapped: the plan (uniform
+ * stride, at most patches_per_rank patches) is executed in n_pieces pieces on compute_stream
+ * into this rank's slab  d_*_all + rank * patches_per_rank * stride;  as soon as a piece is
+ * done, comm_stream exchanges that piece of EVERY rank (grouped in-place broadcasts, one per
+ * root) while the next piece is computed.  On return (asynchronous) compute_stream is ordered
+ * after the exchange.  Every rank must call it with the same patches_per_rank and n_pieces. */
+int slod_plan_execute_allgather(slod_plan *p, slod_comm *c, double *d_basis_all, double *d_premult_all,
+                                size_t patches_per_rank, int n_pieces, void *compute_stream,
+                                void *comm_stream);
+
 /* ---- pieces exposed for parity tests ----------------------------------------------- */
 /* unconstrained patch stiffness (replaces assemble_stiffness with empty constraints,
  * LOD.cc:440-444 -> Diffusion.h:111-207 / Elasticity.h:163-299) as a 9-point block stencil:

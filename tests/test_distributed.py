@@ -35,3 +35,19 @@ def test_sharded_all_gather_matches_single_process(world, problems):
         outs.append(out)
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "DIST_OK" in outs[0]
+
+
+def test_gather_pieces_tile_the_padded_slab():
+    """slod_gather_piece: the pieces of slod_plan_execute_allgather cover a rank's padded slab exactly
+    once, in order, identically on every rank (host-only index calculus; the exchange itself needs
+    RCCL and GPUs: tests/test_gpu_lod_system.py::test_execute_allgather_single_rank)."""
+    import slod_amd
+    for total, world in ((1024, 2), (1024, 3), (17, 2), (5, 8)):
+        ppr = max(slod_amd.partition(total, world, r)[1] - slod_amd.partition(total, world, r)[0] for r in range(world))
+        for n_pieces in (1, 2, 3, 7, ppr, ppr + 3):
+            covered = []
+            for i in range(n_pieces):
+                f, c = slod_amd.gather_piece(ppr, n_pieces, i)
+                assert f + c <= ppr
+                covered += list(range(f, f + c))
+            assert covered == list(range(ppr)), (total, world, n_pieces)

@@ -215,3 +215,35 @@ def test_device_coefficient_sampling_matches_reference_formula(so):
     g.set_coefficient(0, field)
     b0, p0, _ = g.compute_basis(ids)
     assert np.array_equal(b0, b1) and np.array_equal(p0, p1)
+
+
+@pytest.mark.parametrize("n_pieces", [1, 3])
+def test_execute_allgather_single_rank(so, n_pieces):
+    """The C-ABI exchange path (slod_comm_* over RCCL, slod_plan_execute_allgather: pieces computed on
+    one stream, exchanged on another) on ONE rank: bit-identical to slod_plan_execute, and the
+    plain slod_comm_allgather copies the slab.  (Multi-rank runs are the driver's 8-GPU bench.)"""
+    import slod_amd
+    torch, dev = _torch()
+    cfg, g = _mk(so, nref=3, n_sub=4, oversampling=1, stabilize=1)
+    fields = make_fields(so, cfg, "D100")
+    _upload(g, fields)
+    ids = np.arange(g.num_patches, dtype=np.uint32)
+    plan = g.plan(ids)
+    ppr = len(ids) + 3                       # a padded slab, as on ranks with fewer patches
+    ref_b = torch.zeros(ppr * plan.stride, dtype=torch.float64, device=dev)
+    ref_q = torch.zeros_like(ref_b)
+    plan.execute(ref_b.data_ptr(), ref_q.data_ptr())
+    plan.status()
+    comm = slod_amd.Comm(slod_amd.Comm.unique_id(), 1, 0, 0)
+    b = torch.zeros_like(ref_b)
+    q = torch.zeros_like(ref_b)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    plan.execute_allgather(comm, b.data_ptr(), q.data_ptr(), ppr, n_pieces, s1.cuda_stream, s2.cuda_stream)
+    torch.cuda.synchronize()
+    plan.status()
+    assert torch.equal(b, ref_b) and torch.equal(q, ref_q)
+    out = torch.zeros_like(ref_b)
+    comm.allgather(b.data_ptr(), out.data_ptr(), b.numel(), s1.cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(out, b)
+    comm.close()
