@@ -30,6 +30,16 @@ sys.path.insert(0, os.path.join(ROOT, "dealii-slod_amd"))
 
 SEED = 20250614
 C2 = dict(nref=5, n_sub=8, oversampling=2, spacedim=1, stabilize=1)
+# the other BASELINE.json configurations (extra bench lines, never the headline):
+#   C3  2-D Poisson H=1/128, n_sub=16, oversampling 3: 16384 patches SHARDED over the ranks (strong scaling)
+#   C4  2-D elasticity H=1/32, n_sub=8, oversampling 2 (ensemble per rank like C2)
+CONFIGS = {
+    "C2": (C2, "weak", "C2: 2D Poisson SLOD, H=1/32, n_sub=8, oversampling=2"),
+    "C3": (dict(nref=7, n_sub=16, oversampling=3, spacedim=1, stabilize=1), "strong",
+           "C3: 2D Poisson SLOD, H=1/128, n_sub=16, oversampling=3"),
+    "C4": (dict(nref=5, n_sub=8, oversampling=2, spacedim=2, stabilize=1), "weak",
+           "C4: 2D linear elasticity SLOD, H=1/32, n_sub=8, oversampling=2"),
+}
 PEAK_FP64_TFLOPS = 78.6   # MI355X dense fp64 (vector = matrix): half the 157.3 TF fp32 vector peak
 PEAK_HBM_GBPS = 8000.0    # /opt/skills/guides/MI355X_MICROARCH.md
 
@@ -55,14 +65,15 @@ def canonical_counts(slod, gids):
     return flops, nbytes
 
 
-def cpu_baseline(cfg_kw, fields, n_full):
+def cpu_baseline(cfg_kw, fields, n_full, every=1):
     """The C oracle (kind 'port': our CPU restatement, the reference cannot be built here)
-    timed on this box's host cores on a bounded sample of the same workload."""
+    timed on this box's host cores on a bounded sample of the same workload (every `every`-th
+    patch of the configuration)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import slod_oracle as so
     cfg = so.make_cfg(**cfg_kw)
     s = cfg.spacedim
-    ids = np.arange(n_full, dtype=np.int32)
+    ids = np.arange(0, n_full, every, dtype=np.int32)
     sizes = np.array([s * so.patch_info(cfg, int(p)).n_f for p in ids], dtype=np.int64)
     offs = np.concatenate([[0], np.cumsum(sizes)[:-1]])
     total = int(sizes.sum())
@@ -91,8 +102,9 @@ def cpu_baseline(cfg_kw, fields, n_full):
         if tall > 6.0 or reps >= 400:
             break
     return {"value": reps * len(ids) / tall, "unit": "patches/s", "cores": cores, "kind": "port",
-            "sample": "all %d patches of C2 x %d passes, OpenMP over patches (%.1f s wall); "
-                      "1 thread on every 8th patch: %.1f patches/s" % (len(ids), reps, tall, len(sub) / t1),
+            "sample": "%d patches (every %d-th of the configuration) x %d passes, OpenMP over patches "
+                      "(%.1f s wall); 1 thread on every 8th of those: %.1f patches/s"
+                      % (len(ids), every, reps, tall, len(sub) / t1),
             "value_1thread": len(sub) / t1}
 
 
@@ -104,7 +116,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the two-stream measurement")
     ap.add_argument("--dist", default="D1e4", choices=["D100", "D1e4"])
+    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS),
+                    help="BASELINE.json configuration (C2 = the headline metric's; C3, C4: extra lines)")
     args = ap.parse_args()
+    CFG, scaling, cfg_label = CONFIGS[args.config]
 
     import torch
     import slod_amd
@@ -125,10 +140,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    # ---- workload: ensemble of `world` realisations of C2, this rank's contiguous block
-    slod = slod_amd.Slod(n_problems=world, device=local_rank, **C2)
+    # ---- workload.  weak: ensemble of `world` realisations of the configuration; strong (C3):
+    #      ONE realisation whose patches are sharded.  Either way: this rank's contiguous block
+    n_prob = world if scaling == "weak" else 1
+    slod = slod_amd.Slod(n_problems=n_prob, device=local_rank, **CFG)
     NP = slod.num_patches
-    total = NP * world
+    total = NP * n_prob
     begin, end = slod_amd.partition(total, world, rank)     # LOD.cc:116-118
     gids = np.arange(begin, end, dtype=np.uint32)
     from slod_amd.synthetic import fill_coefficient
@@ -136,9 +153,10 @@ def main():
     probs = sorted(set(int(g) // NP for g in gids))
     fields = {}
     for pb in probs:
-        fields[pb] = fill_coefficient(SEED + 1000 * pb, args.dist, slod.NE)
-        t = torch.from_numpy(fields[pb]).to(dev)                  # resident in HBM before timing
-        slod.set_coefficient_device(0, t.data_ptr(), t.numel(), problem=pb)
+        fields[pb] = [fill_coefficient(SEED + 1000 * pb + f, args.dist, slod.NE) for f in range(slod.spacedim)]
+        for f in range(slod.spacedim):                            # elasticity: lambda = seed, mu = seed + 1
+            t = torch.from_numpy(fields[pb][f]).to(dev)           # resident in HBM before timing
+            slod.set_coefficient_device(f, t.data_ptr(), t.numel(), problem=pb)
     from slod_amd import distributed as sd
     plan = slod.plan(gids)                                        # uniform stride -> all-gather slabs
     n_local = len(gids)
@@ -219,25 +237,31 @@ def main():
         achieved_tf = flops / solve_s / 1e12
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.config == "C2":
             try:
                 traffic = json.load(open(tpath)).get("k_solve_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
-            "metric": "SLOD patches/sec (basis built), 2D Poisson H=1/32 n_sub=8 oversampling 2",
+            "metric": "SLOD patches/sec (basis built), 2D Poisson H=1/32 n_sub=8 oversampling 2" if args.config == "C2"
+                      else "SLOD patches/sec (basis built), " + cfg_label,
             "value": total * args.steps / elapsed,
             "unit": "patches/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C2: 2D Poisson SLOD, H=1/32, n_sub=8, oversampling=2, "
-                                   "%s coefficient (contrast %g), %d patches per GPU "
-                                   "(ensemble of %d realisations, contiguous patch blocks)"
-                                   % (args.dist, hi / lo, n_local, world),
+            "config": {"workload": cfg_label + ", %s coefficient (contrast %g), %d patches on rank 0 (%s, contiguous "
+                                   "patch blocks)" % (args.dist, hi / lo, n_local,
+                                                      "ensemble of %d realisations" % world if scaling == "weak"
+                                                      else "%d patches sharded over %d ranks" % (total, world)),
                        "patches_per_gpu": n_local, "parallelism": "patch-sharded x%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "k_solve_tw<5,1>" + (" (stencil assembly and selection stage fused in)" if ks[2] < 0.05 * ks[1] and ks[0] < 0.05 * ks[1] else (" (selection stage fused in)" if ks[2] < 0.05 * ks[1] else "")),
+            # the kernel's roof is the fp64 rate (on MI355X the vector and the matrix pipe have the
+            # same 78.6 TFLOP/s): "mfma" names that peak; what actually limits the kernel today is
+            # the instruction issue / dependent-chain latency of its Gauss-Jordan waves
+            "roofline": {"bound": "mfma",
+                         "limiter": "fp64 instruction issue and dependent-chain latency (VALU Gauss-Jordan waves)",
+                         "kernel": "k_solve_%s" % os.environ.get("SLOD_SOLVE", "tw") + (" (stencil assembly and selection stage fused in)" if ks[2] < 0.05 * ks[1] and ks[0] < 0.05 * ks[1] else (" (selection stage fused in)" if ks[2] < 0.05 * ks[1] else "")),
                          "achieved": achieved_tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / PEAK_FP64_TFLOPS, "traffic": traffic,
                          "algorithmic_flops_per_launch": flops,
@@ -249,7 +273,7 @@ def main():
             "pipelined": pipelined,
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(C2, [fields[probs[0]]], NP)
+            out["cpu_baseline"] = cpu_baseline(CFG, fields[probs[0]], NP, every={"C2": 1, "C3": 256, "C4": 8}[args.config])
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

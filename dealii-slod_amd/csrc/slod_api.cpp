@@ -32,7 +32,8 @@ struct slod_plan
   slod_handle               *h = nullptr;
   size_t                     n = 0;
   std::vector<SlodPatchDesc> desc;
-  SlodPatchDesc             *d_desc = nullptr;
+  SlodPatchDesc             *d_desc = nullptr;     // the caller's order (pieces of slod_plan_execute_allgather)
+  SlodPatchDesc             *d_desc_bal = nullptr; // launch order balanced over the CUs (slod_plan_execute)
   int                        m_max = 0, L_max = 0, nc_max = 0, nb_max = 0, nn_max = 0, nf_max = 0;
   int                        nb_buf = 0; // rows of k_select's boundary-trace buffer
   size_t                     stride = 0, out_size = 0;
@@ -214,12 +215,12 @@ int slod_ensure_device(slod_handle *h)
 
 namespace
 {
-  SlodKernelArgs make_args(const slod_plan *p, size_t first, double *d_basis, double *d_premult)
+  SlodKernelArgs make_args(const slod_plan *p, size_t first, double *d_basis, double *d_premult, bool balanced)
   {
     const slod_handle *h = p->h;
     SlodKernelArgs     a;
     std::memset(&a, 0, sizeof(a));
-    a.desc        = p->d_desc + first;
+    a.desc        = (balanced && p->d_desc_bal ? p->d_desc_bal : p->d_desc) + first;
     a.coef0       = h->d_coef[0];
     a.coef1       = h->d_coef[1];
     a.coef_stride = (size_t)h->NE * h->NE * 4;
@@ -251,7 +252,7 @@ namespace
     a.basis     = d_basis;
     a.premult   = d_premult;
     a.status    = p->d_status;
-    a.pdiag     = p->d_pdiag ? p->d_pdiag + first * (size_t)h->cfg.spacedim : nullptr;
+    a.pdiag     = p->d_pdiag;
     return a;
   }
 } // namespace
@@ -261,10 +262,10 @@ namespace
   // the launches of the patches [first, first + cnt) of a plan (cnt <= chunk: one workspace slot per
   // workgroup); ev (optional): four events around the three stages
   hipError_t launch_range(slod_plan *p, size_t first, int cnt, double *d_basis, double *d_premult, hipStream_t st,
-                          hipEvent_t *ev)
+                          hipEvent_t *ev, bool balanced)
   {
     const int      s = p->h->cfg.spacedim;
-    SlodKernelArgs a = make_args(p, first, d_basis, d_premult);
+    SlodKernelArgs a = make_args(p, first, d_basis, d_premult, balanced);
     hipError_t     e = ev ? hipEventRecord(ev[0], st) : hipSuccess;
     if (e == hipSuccess && !p->choice.fuse_assemble)
       e = slod_launch_assemble(s, a, cnt, st);
@@ -513,6 +514,7 @@ int slod_plan_create(slod_handle *h, const uint32_t *gids, size_t n, const uint6
         }
       SlodPatchDesc d = make_desc(h, gids[k]);
       d.out_off       = offsets ? offsets[k] : (uint64_t)k * p->stride;
+      d.plan_index    = (uint32_t)k;
       const int nn    = (d.nx + 1) * (d.ny + 1);
       p->m_max        = std::max(p->m_max, (int)d.m);
       p->L_max        = std::max(p->L_max, (int)d.L);
@@ -579,6 +581,34 @@ int slod_plan_create(slod_handle *h, const uint32_t *gids, size_t n, const uint6
   ok       = ok && hipMemset(p->d_pdiag, 0, n * (size_t)s * sizeof(SlodPatchDiag)) == hipSuccess;
   ok = ok && hipMemcpy(p->d_desc, p->desc.data(), n * sizeof(SlodPatchDesc), hipMemcpyHostToDevice) ==
                hipSuccess;
+  if (ok && slod_read_tuning().balance && n > 1)
+    {
+      // Launch order.  All workgroups of a launch are resident at once (a few per CU) and the step
+      // ends with the slowest CU; measured on MI355X (tools/patch_timeline.py) the blocks b, b + n_cu,
+      // b + 2 n_cu, ... share a CU.  Patches sorted by estimated cost (canonical solve flops, rim
+      // patches are cheaper) and dealt in a snake over rows of n_cu give every CU the same mix.
+      int n_cu = 256;
+      (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->cfg.device);
+      n_cu = std::max(n_cu, 1);
+      std::vector<std::pair<double, uint32_t>> cost(n);
+      for (size_t k = 0; k < n; ++k)
+        {
+          const SlodPatchDesc &d = p->desc[k];
+          const double ni = (double)d.m * d.L, b = (double)d.m + s - 1;
+          cost[k] = {-(ni * (b * b + 3 * b) + 4.0 * d.n_c * ni * b + 200.0 * d.n_b * d.n_c), (uint32_t)k};
+        }
+      std::stable_sort(cost.begin(), cost.end());
+      std::vector<SlodPatchDesc> bal(n);
+      for (size_t r = 0; r < n; ++r)
+        {
+          const size_t row = r / (size_t)n_cu, col = r % (size_t)n_cu;
+          const size_t len = std::min<size_t>((size_t)n_cu, n - row * (size_t)n_cu);
+          const size_t pos = row * (size_t)n_cu + ((row & 1) ? len - 1 - col : col);
+          bal[pos]         = p->desc[cost[r].second];
+        }
+      ok = ok && hipMalloc((void **)&p->d_desc_bal, n * sizeof(SlodPatchDesc)) == hipSuccess;
+      ok = ok && hipMemcpy(p->d_desc_bal, bal.data(), n * sizeof(SlodPatchDesc), hipMemcpyHostToDevice) == hipSuccess;
+    }
   ok = ok && hipMemset(p->d_status, 0, sizeof(int32_t)) == hipSuccess;
   p->n_chunks = (n + p->chunk - 1) / p->chunk;
   p->ev.assign(4 * p->n_chunks, nullptr);
@@ -603,6 +633,8 @@ void slod_plan_destroy(slod_plan *p)
       (void)hipEventDestroy(ev);
   if (p->d_desc)
     (void)hipFree(p->d_desc);
+  if (p->d_desc_bal)
+    (void)hipFree(p->d_desc_bal);
   if (p->ws_st)
     (void)hipFree(p->ws_st);
   if (p->ws_v)
@@ -642,7 +674,7 @@ int slod_plan_execute(slod_plan *p, double *d_basis, double *d_premult, void *hi
   (void)s;
   for (size_t first = 0; first < p->n && e == hipSuccess; first += p->chunk, ++ci)
     e = launch_range(p, first, (int)std::min(p->chunk, p->n - first), d_basis, d_premult, st,
-                     &p->ev[4 * ((p->n_exec % (size_t)p->depth) * p->n_chunks + ci)]);
+                     &p->ev[4 * ((p->n_exec % (size_t)p->depth) * p->n_chunks + ci)], true);
   if (e != hipSuccess)
     return hip_fail(h, e, "slod_plan_execute");
   p->ran = true;
@@ -1082,7 +1114,7 @@ int slod_plan_execute_allgather(slod_plan *p, slod_comm *c, double *d_basis_all,
       // this rank's patches of the piece (the padded tail of a rank with fewer patches stays as it is)
       const size_t mine = first < p->n ? std::min<size_t>(count, p->n - first) : 0;
       for (size_t k = 0; k < mine && e == hipSuccess; k += p->chunk)
-        e = launch_range(p, first + k, (int)std::min(p->chunk, mine - k), mb, mp, cs, nullptr);
+        e = launch_range(p, first + k, (int)std::min(p->chunk, mine - k), mb, mp, cs, nullptr, false);
       // the exchange of piece i overlaps the computation of piece i + 1: the communication stream
       // waits for the piece only
       hipEvent_t ev = nullptr;

@@ -20,6 +20,7 @@ struct SlodPatchDesc
   int32_t  m, L;     // dofs per grid line, number of interior lines (m <= L)
   int32_t  n_c, n_b; // coarse dofs, id-99 boundary dofs
   int32_t  prob;     // coefficient realisation
+  uint32_t plan_index; // position of the patch in the caller's list (diagnostics slot)
   uint64_t out_off;  // offset (doubles) of this patch in basis / premult
 };
 
@@ -82,7 +83,7 @@ struct SlodKernelArgs
   double  *basis;
   double  *premult;
   int32_t *status;
-  SlodPatchDiag *pdiag; // [patches of the launch][S]
+  SlodPatchDiag *pdiag; // [patches of the PLAN][S], indexed by SlodPatchDesc::plan_index
 };
 
 enum SlodSolverKind : int32_t
@@ -99,6 +100,7 @@ struct SlodTuning
   int solver = 0;        // 0 = automatic, else a SlodSolverKind
   int fuse_select = 1, fuse_assemble = 1, fuse_m = 0;
   int twisted = -1;      // coop kernel only: -1 = automatic
+  int balance = 1;       // launch order balanced over the CUs (SLOD_BALANCE=0: the caller's order)
   int debug = 0;
 };
 struct SlodSolveChoice

@@ -11,6 +11,7 @@
 //   SLOD_SOLVE=mf|tw|ws|coop  force a kernel family       SLOD_FUSE_SELECT=0  selection as its own launch
 //   SLOD_FUSE_ASSEMBLE=0      stencil assembly as its own launch
 //   SLOD_FUSE_M=1 (ws only)   SLOD_TWISTED=0|1 (coop only) SLOD_DEBUG=1 print the choice
+//   SLOD_BALANCE=0            launch the patches in the caller's order (default: balanced over the CUs)
 SlodTuning slod_read_tuning()
 {
   SlodTuning t;
@@ -25,6 +26,8 @@ SlodTuning slod_read_tuning()
     t.fuse_m = atoi(e) ? 1 : 0;
   if (const char *e = getenv("SLOD_TWISTED"))
     t.twisted = atoi(e) ? 1 : 0;
+  if (const char *e = getenv("SLOD_BALANCE"))
+    t.balance = atoi(e) ? 1 : 0;
   if (const char *e = getenv("SLOD_DEBUG"))
     t.debug = atoi(e) ? 1 : 0;
   return t;

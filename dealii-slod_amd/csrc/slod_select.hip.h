@@ -1148,7 +1148,7 @@ namespace
               }
           }
         if (tid == 0 && A.pdiag)
-          A.pdiag[(size_t)patch * S + dsel] = pdg;
+          A.pdiag[(size_t)d.plan_index * S + dsel] = pdg;
         __syncthreads();
         stamp(9);
         // ---- c = D gamma (LOD.cc:727-743 / 576-577)

@@ -56,7 +56,14 @@ namespace
     auto      line_of = [&](int c, int t) { return c == 0 ? t : L - 1 - t; }; // t == n_c gives mid
 
     if ((SLOD_DG(A, (1 << 20))) && tid == 0)
-      A.ms[(size_t)blockIdx.x * A.nc_max * A.nc_max] = (double)wall_clock64();
+      {
+        A.ms[(size_t)blockIdx.x * A.nc_max * A.nc_max] = (double)wall_clock64();
+        if (A.nc_max * A.nc_max >= 16) // where the workgroup runs: HW_ID (reg 4) and XCC_ID (reg 20)
+          {
+            A.ms[(size_t)blockIdx.x * A.nc_max * A.nc_max + 12] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+            A.ms[(size_t)blockIdx.x * A.nc_max * A.nc_max + 13] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 20);
+          }
+      }
     // Fused stencil assembly: the workgroup builds the stencil planes of its own patch (k_assemble
     // as a device function), saving a launch and its tail; the planes still go through the
     // workspace, which the band fetches and the selection stage read back

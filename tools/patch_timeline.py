@@ -62,3 +62,20 @@ ph = dict(M=r[:, 3] - t_end_solve, D=r[:, 4] - r[:, 3], fill=r[:, 5], mult=r[:, 
 slow = ph["svd"] > 20.0
 for name, m in (("fast path", ~slow), ("SVD fallback", slow)):
     print("%-13s n=%3d " % (name, m.sum()) + "  ".join("%s %.1f" % (k, v[m].mean()) for k, v in ph.items()))
+
+# placement: which patches share a CU (HW_ID: CU_ID bits 11:8, SH_ID 12, SE_ID 15:13; XCC_ID bits 3:0)
+hw = buf.reshape(len(ids), ncm * ncm)[:, 12].astype(np.int64)
+xcc = buf.reshape(len(ids), ncm * ncm)[:, 13].astype(np.int64) & 15
+cu = (xcc << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15)
+groups = {}
+for k in range(len(ids)):
+    groups.setdefault(int(cu[k]), []).append(k)
+sizes = np.array([len(v) for v in groups.values()])
+print("distinct CUs %d, workgroups per CU: min %d max %d" % (len(groups), sizes.min(), sizes.max()))
+for key in list(sorted(groups))[:6]:
+    print("  cu %5d: blocks %s" % (key, groups[key]))
+end = tt[:, 2] - t0
+per_cu_end = np.array([end[v].max() for v in groups.values()])
+print("per-CU finish time (us): mean %.1f  min %.1f  max %.1f" % (per_cu_end.mean(), per_cu_end.min(), per_cu_end.max()))
+work = (tt[:, 2] - tt[:, 0])
+print("sum of patch times per CU: mean %.1f max %.1f" % (np.mean([work[v].sum() for v in groups.values()]), np.max([work[v].sum() for v in groups.values()])))
