@@ -64,6 +64,8 @@ namespace
             A.ms[(size_t)blockIdx.x * A.nc_max * A.nc_max + 13] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 20);
           }
       }
+    if ((SLOD_DG(A, (1 << 20))) && lane == 0 && A.nc_max * A.nc_max >= 24) // SIMD of each wave (HW_ID bits 5:4)
+      A.ms[(size_t)blockIdx.x * A.nc_max * A.nc_max + 20 + wave] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 4);
     // Fused stencil assembly: the workgroup builds the stencil planes of its own patch (k_assemble
     // as a device function), saving a launch and its tail; the planes still go through the
     // workspace, which the band fetches and the selection stage read back

@@ -79,3 +79,17 @@ per_cu_end = np.array([end[v].max() for v in groups.values()])
 print("per-CU finish time (us): mean %.1f  min %.1f  max %.1f" % (per_cu_end.mean(), per_cu_end.min(), per_cu_end.max()))
 work = (tt[:, 2] - tt[:, 0])
 print("sum of patch times per CU: mean %.1f max %.1f" % (np.mean([work[v].sum() for v in groups.values()]), np.max([work[v].sum() for v in groups.values()])))
+
+# wave -> SIMD placement (HW_ID bits 5:4) of the four roles: GJ chain 0/1 (roles 0,1), helpers (2,3)
+if ncm * ncm >= 24:
+    simd = (buf.reshape(len(ids), ncm * ncm)[:, 20:24].astype(np.int64) >> 4) & 3
+    import collections
+    print("role->SIMD patterns:", collections.Counter(tuple(r) for r in simd).most_common(6))
+    for key in list(sorted(groups))[:4]:
+        print("  cu %5d: role SIMDs per workgroup %s" % (key, [tuple(simd[k]) for k in groups[key]]))
+    gj = np.zeros((len(groups), 4), int)
+    for i, v in enumerate(groups.values()):
+        for k in v:
+            gj[i, simd[k, 0]] += 1
+            gj[i, simd[k, 1]] += 1
+    print("GJ waves per SIMD (per CU): histogram of max", np.bincount(gj.max(axis=1)))
