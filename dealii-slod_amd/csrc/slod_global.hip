@@ -298,6 +298,108 @@ namespace
     sc->rr     = 0.0;
   }
 
+  // ---- fine FEM reference problem on the global fine grid (assemble_and_solve_fem_problem,
+  // LOD.cc:1004-1094): load vector of assemble_stiffness (Diffusion.h:149-193) and a matrix-free
+  // Jacobi-CG on the 9-point block stencil planes of k_assemble (whole domain = one "patch").
+  // Dirichlet nodes (every side of the domain, LOD.cc:1021) are identity rows with value 0.
+  __global__ void k_fem_rhs(int NE, int s, double h2q, const double *f_qp, double *rhs)
+  {
+    const int np = NE + 1, node = blockIdx.x * 256 + threadIdx.x;
+    if (node >= np * np)
+      return;
+    const int  ix = node % np, iy = node / np;
+    const bool bnd = ix == 0 || iy == 0 || ix == NE || iy == NE;
+    for (int c = 0; c < s; ++c)
+      {
+        double acc = 0.0;
+        if (!bnd)
+          for (int ay = 0; ay < 2; ++ay)
+            for (int ax = 0; ax < 2; ++ax)
+              {
+                const int    ex = ix - ax, ey = iy - ay; // element that has this node as its corner (ax, ay)
+                const size_t ge = ((size_t)ey * NE + ex) * 4;
+                for (int q = 0; q < 4; ++q)
+                  {
+                    constexpr double g0 = 0.21132486540518711775, g1 = 0.78867513459481288225; // (1 -+ 1/sqrt 3)/2
+                    const double     xi = (q & 1) ? g1 : g0, eta = (q & 2) ? g1 : g0;
+                    const double     N  = (ax ? xi : 1.0 - xi) * (ay ? eta : 1.0 - eta);
+                    acc += N * (f_qp ? f_qp[(size_t)c * NE * NE * 4 + ge + q] : 1.0) * h2q;
+                  }
+              }
+        rhs[(size_t)node * s + c] = acc;
+      }
+  }
+  // y = A x on the interior nodes (x, y: [(NE+1)^2][s]); boundary rows: y = x.  Also accumulates
+  // x.y into sc->pAp.  st: planes [(dir*s + a)*s + b][nn], dir = (dy+1)*3 + dx+1.
+  __global__ void k_fem_spmv_dot(int NE, int s, const double *st, const double *x, double *y, CgScalars *sc)
+  {
+    const int    np = NE + 1, nn = np * np, node = blockIdx.x * 256 + threadIdx.x;
+    double       part = 0.0;
+    if (node < nn)
+      {
+        const int  ix = node % np, iy = node / np;
+        const bool bnd = ix == 0 || iy == 0 || ix == NE || iy == NE;
+        for (int a = 0; a < s; ++a)
+          {
+            double acc = 0.0;
+            if (bnd)
+              acc = x[(size_t)node * s + a];
+            else
+              for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx)
+                  {
+                    const int jx = ix + dx, jy = iy + dy;
+                    if (jx == 0 || jy == 0 || jx == NE || jy == NE)
+                      continue; // constrained neighbour: value 0
+                    const int dir = (dy + 1) * 3 + dx + 1, nb = jx + jy * np;
+                    for (int b = 0; b < s; ++b)
+                      acc = fma(st[(size_t)((dir * s + a) * s + b) * nn + node], x[(size_t)nb * s + b], acc);
+                  }
+            y[(size_t)node * s + a] = acc;
+            part += acc * x[(size_t)node * s + a];
+          }
+      }
+    for (int off = 32; off > 0; off >>= 1)
+      part += __shfl_xor(part, off, 64);
+    if ((threadIdx.x & 63) == 0 && part != 0.0)
+      atomicAdd(&sc->pAp, part);
+  }
+  __global__ void k_fem_init(int NE, int s, const double *st, const double *rhs, double *x, double *r, double *z, double *pv,
+                             double *dinv, CgScalars *sc)
+  {
+    const int np = NE + 1, nn = np * np, node = blockIdx.x * 256 + threadIdx.x;
+    double    a = 0.0, b = 0.0;
+    if (node < nn)
+      {
+        const int  ix = node % np, iy = node / np;
+        const bool bnd = ix == 0 || iy == 0 || ix == NE || iy == NE;
+        for (int c = 0; c < s; ++c)
+          {
+            const size_t i    = (size_t)node * s + c;
+            const double diag = bnd ? 1.0 : st[(size_t)((4 * s + c) * s + c) * nn + node];
+            const double f    = bnd ? 0.0 : rhs[i];
+            dinv[i]           = diag != 0.0 ? 1.0 / diag : 1.0;
+            x[i]              = 0.0;
+            r[i]              = f;
+            z[i]              = dinv[i] * f;
+            pv[i]             = z[i];
+            a += f * z[i];
+            b += f * f;
+          }
+      }
+    for (int off = 32; off > 0; off >>= 1)
+      {
+        a += __shfl_xor(a, off, 64);
+        b += __shfl_xor(b, off, 64);
+      }
+    if ((threadIdx.x & 63) == 0)
+      {
+        atomicAdd(&sc->rz, a);
+        atomicAdd(&sc->rhs2, b);
+        atomicAdd(&sc->rr, b);
+      }
+  }
+
   // ---- inputs produced on the device ----
   __global__ void k_patch_info(const SlodGrid G, const uint32_t *ids, int n_ids, slod_patch_info *out)
   {
@@ -605,6 +707,130 @@ int slod_sample_coefficient(slod_handle *h, uint32_t problem, int field, const d
     return slod_hip_fail(h, e, "slod_sample_coefficient");
   h->coef_set[(size_t)problem * 2 + field] = 1;
   return SLOD_OK;
+}
+
+int slod_fem_rhs(slod_handle *h, const double *d_f_qp, double *d_fine_rhs, void *hip_stream)
+{
+  if (!h || !d_fine_rhs)
+    return SLOD_ERR_ARGUMENT;
+  if (const int rc = slod_ensure_device(h))
+    return rc;
+  (void)hipSetDevice(h->cfg.device);
+  hipStream_t  st = hip_stream ? (hipStream_t)hip_stream : h->stream;
+  const int    nn = (h->NE + 1) * (h->NE + 1);
+  const double hf = 1.0 / h->NE;
+  hipLaunchKernelGGL(k_fem_rhs, dim3((nn + 255) / 256), dim3(256), 0, st, h->NE, h->cfg.spacedim, hf * hf * 0.25, d_f_qp,
+                     d_fine_rhs);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SLOD_OK : slod_hip_fail(h, e, "slod_fem_rhs");
+}
+
+int slod_fem_solve(slod_handle *h, uint32_t problem, const double *d_fine_rhs, double *d_fine_u, double rel_tol,
+                   int max_iterations, double *rel_residual)
+{
+  if (!h || !d_fine_rhs || !d_fine_u || max_iterations < 0)
+    return SLOD_ERR_ARGUMENT;
+  if (problem >= (uint32_t)h->cfg.n_problems)
+    return slod_fail(h, SLOD_ERR_ARGUMENT, "slod_fem_solve: problem out of range");
+  const int s = h->cfg.spacedim;
+  for (int f = 0; f < s; ++f)
+    if (!h->coef_set[(size_t)problem * 2 + f])
+      return slod_fail(h, SLOD_ERR_ARGUMENT, "slod_fem_solve: coefficient not set");
+  if (const int rc = slod_ensure_device(h))
+    return rc;
+  (void)hipSetDevice(h->cfg.device);
+  hipStream_t   st = h->stream;
+  const int     NE = h->NE, nn = (NE + 1) * (NE + 1), nblk = (nn + 255) / 256;
+  const size_t  nrow = (size_t)nn * s;
+  double       *planes = nullptr, *work = nullptr;
+  SlodPatchDesc *d_desc = nullptr;
+  CgScalars    *sc = nullptr, hs;
+  hipError_t    e = hipMalloc((void **)&planes, (size_t)9 * s * s * nn * sizeof(double));
+  if (e == hipSuccess)
+    e = hipMalloc((void **)&work, 5 * nrow * sizeof(double));
+  if (e == hipSuccess)
+    e = hipMalloc((void **)&d_desc, sizeof(SlodPatchDesc));
+  if (e == hipSuccess)
+    e = hipMalloc((void **)&sc, sizeof(CgScalars));
+  if (e == hipSuccess)
+    e = hipMemsetAsync(sc, 0, sizeof(CgScalars), st);
+  int it = 0;
+  if (e == hipSuccess)
+    {
+      // the whole domain as one patch of k_assemble: NE x NE fine elements at the origin
+      SlodPatchDesc d;
+      std::memset(&d, 0, sizeof(d));
+      d.nx   = NE;
+      d.ny   = NE;
+      d.prob = (int32_t)problem;
+      e      = hipMemcpyAsync(d_desc, &d, sizeof(d), hipMemcpyHostToDevice, st);
+      SlodKernelArgs a;
+      std::memset(&a, 0, sizeof(a));
+      a.desc        = d_desc;
+      a.coef0       = h->d_coef[0];
+      a.coef1       = h->d_coef[1];
+      a.coef_stride = (size_t)NE * NE * 4;
+      a.NE          = NE;
+      a.n_sub       = h->cfg.n_subdivisions;
+      a.st          = planes;
+      a.st_stride   = (size_t)9 * s * s * nn;
+      a.nn_max      = nn;
+      if (e == hipSuccess)
+        e = slod_launch_assemble(s, a, 1, st);
+    }
+  if (e == hipSuccess)
+    {
+      double *r = work, *z = work + nrow, *pv = work + 2 * nrow, *Ap = work + 3 * nrow, *dinv = work + 4 * nrow;
+      hipLaunchKernelGGL(k_fem_init, dim3(nblk), dim3(256), 0, st, NE, s, planes, d_fine_rhs, d_fine_u, r, z, pv, dinv, sc);
+      e = hipMemcpyAsync(&hs, sc, sizeof(hs), hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess)
+        e = hipStreamSynchronize(st);
+      const double rhs2 = hs.rhs2;
+      double       rr   = hs.rr;
+      if (e == hipSuccess)
+        {
+          hs.rr = 0.0;
+          hs.pAp = 0.0;
+          hs.rz_new = 0.0;
+          e = hipMemcpyAsync(sc, &hs, sizeof(hs), hipMemcpyHostToDevice, st);
+        }
+      const int nb1 = (int)((nrow + 255) / 256);
+      while (e == hipSuccess && it < max_iterations && rhs2 > 0.0 && rr > rel_tol * rel_tol * rhs2)
+        {
+          // a burst of iterations per convergence check: the scalars stay on the device in between
+          const int burst = std::min(32, max_iterations - it);
+          for (int b = 0; b < burst; ++b)
+            {
+              hipLaunchKernelGGL(k_fem_spmv_dot, dim3(nblk), dim3(256), 0, st, NE, s, planes, pv, Ap, sc);
+              hipLaunchKernelGGL(k_cg_update_xr, dim3(nb1), dim3(256), 0, st, (int)nrow, pv, Ap, dinv, d_fine_u, r, z, sc);
+              hipLaunchKernelGGL(k_cg_update_p, dim3(nb1), dim3(256), 0, st, (int)nrow, z, pv, sc);
+              if (b + 1 < burst)
+                hipLaunchKernelGGL(k_cg_rotate, dim3(1), dim3(1), 0, st, sc);
+            }
+          it += burst;
+          e = hipMemcpyAsync(&hs, sc, sizeof(hs), hipMemcpyDeviceToHost, st);
+          if (e == hipSuccess)
+            e = hipStreamSynchronize(st);
+          rr = hs.rr;
+          if (e == hipSuccess)
+            hipLaunchKernelGGL(k_cg_rotate, dim3(1), dim3(1), 0, st, sc);
+        }
+      if (e == hipSuccess)
+        e = hipStreamSynchronize(st);
+      if (rel_residual)
+        *rel_residual = rhs2 > 0.0 ? std::sqrt(rr / rhs2) : 0.0;
+    }
+  if (planes)
+    (void)hipFree(planes);
+  if (work)
+    (void)hipFree(work);
+  if (d_desc)
+    (void)hipFree(d_desc);
+  if (sc)
+    (void)hipFree(sc);
+  if (e != hipSuccess)
+    return slod_hip_fail(h, e, "slod_fem_solve");
+  return it;
 }
 
 } // extern "C"

@@ -104,6 +104,8 @@ def load():
     lib.slod_lod_rhs.argtypes = [vp, u32p, C.c_size_t, vp, C.c_size_t, vp, vp, vp]
     lib.slod_lod_solve.argtypes = [vp, vp, vp, vp, vp, C.c_double, C.c_int, dp]
     lib.slod_lod_reconstruct.argtypes = [vp, vp, C.c_size_t, vp, vp, vp]
+    lib.slod_fem_rhs.argtypes = [vp, vp, vp, vp]
+    lib.slod_fem_solve.argtypes = [vp, C.c_uint32, vp, vp, C.c_double, C.c_int, dp]
     lib.slod_device_patch_layout.argtypes = [vp, u32p, C.c_size_t, C.POINTER(PatchInfo)]
     lib.slod_sample_coefficient.argtypes = [vp, C.c_uint32, C.c_int, vp, C.c_int]
     lib.slod_assemble_stiffness_for_patch.argtypes = [vp, C.c_uint32, dp]
@@ -322,6 +324,17 @@ class Slod:
 
     def lod_reconstruct(self, d_basis, stride, d_u, d_fine, stream=None):
         self._check(self.lib.slod_lod_reconstruct(self.h, d_basis, stride, d_u, d_fine, stream))
+
+    def fem_rhs(self, d_f_qp, d_fine_rhs, stream=None):
+        """Fine FEM load vector (d_f_qp = None: f = 1)."""
+        self._check(self.lib.slod_fem_rhs(self.h, d_f_qp, d_fine_rhs, stream))
+
+    def fem_solve(self, d_fine_rhs, d_fine_u, rel_tol=1e-12, max_iterations=20000, problem=0):
+        res = C.c_double()
+        it = self.lib.slod_fem_solve(self.h, problem, d_fine_rhs, d_fine_u, rel_tol, max_iterations, C.byref(res))
+        if it < 0:
+            self._check(it)
+        return it, res.value
 
     def device_patch_layout(self, ids):
         ids = np.ascontiguousarray(ids, dtype=np.uint32)

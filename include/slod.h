@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SLOD_ABI_VERSION 3
+#define SLOD_ABI_VERSION 4
 
 typedef enum
 {
@@ -197,6 +197,22 @@ int slod_lod_solve(slod_handle *h, const double *d_values, const uint32_t *d_col
  * = sum over patches covering the node, sum_d phi_{p,d}(node, c) u[p s + d]. */
 int slod_lod_reconstruct(slod_handle *h, const double *d_basis, size_t stride, const double *d_u,
                          double *d_fine, void *hip_stream);
+
+/* ---- fine FEM reference problem (assemble_and_solve_fem_problem, LOD.cc:1004-1094) ----
+ * What the reference compares the LOD solution with (compare_lod_with_fem, LOD.cc:1240-1378).
+ * fem_rhs of assemble_stiffness (Diffusion.h:149-193) on the global fine grid, [(NE+1)^2][s],
+ * zero on the Dirichlet nodes (all sides, LOD.cc:1021): d_f_qp = right-hand side function at the
+ * quadrature points, DEVICE, [s][NE][NE][4] with the layout of slod_set_coefficient, or NULL for
+ * f = (1,..,1) (the example's "fem rhs l2 norm = 0.109375", tests/Poisson_LOD_Example.output).
+ * Asynchronous on hip_stream. */
+int slod_fem_rhs(slod_handle *h, const double *d_f_qp, double *d_fine_rhs, void *hip_stream);
+/* Fine FEM solution for the coefficient of `problem` (the reference: CG + AMG, LOD.cc:1070-1075;
+ * here a matrix-free Jacobi-preconditioned CG on the 9-point stencil planes, all on the device).
+ * Returns the iteration count (>= 0) or a negative slod_status; *rel_residual (HOST, may be
+ * NULL) receives ||r|| / ||rhs||.  d_fine_u: DEVICE, [(NE+1)^2][s], zero on the boundary.
+ * Synchronises. */
+int slod_fem_solve(slod_handle *h, uint32_t problem, const double *d_fine_rhs, double *d_fine_u, double rel_tol,
+                   int max_iterations, double *rel_residual);
 
 /* ---- inputs of the path produced on the device --------------------------------------
  * create_patches + create_mesh_for_patch + fill_dofs_indices_vector (LOD.cc:122-244,

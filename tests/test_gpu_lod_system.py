@@ -247,3 +247,119 @@ def test_execute_allgather_single_rank(so, n_pieces):
     torch.cuda.synchronize()
     assert torch.equal(out, b)
     comm.close()
+
+
+# ---- fine FEM reference problem (assemble_and_solve_fem_problem, LOD.cc:1004-1094)
+
+def _fem_reference(NE, s, fields, fq=None):
+    """Global fine stiffness and load vector with scipy (element matrices of oracle/slod_numpy.py),
+    Dirichlet rows/columns removed; returns (A_II, f_I, interior index array)."""
+    import scipy.sparse as sp
+    import slod_numpy as sn
+    NEp = NE + 1
+    rows, cols, vals = [], [], []
+    f = np.zeros(NEp * NEp * s)
+    hf = 1.0 / NE
+    g = (sn.G0, sn.G1)
+    for ey in range(NE):
+        for ex in range(NE):
+            ge = (ey * NE + ex) * 4
+            K = sn.element_matrix(s, [fld[ge:ge + 4] for fld in fields])
+            nodes = [ex + ey * NEp, ex + 1 + ey * NEp, ex + (ey + 1) * NEp, ex + 1 + (ey + 1) * NEp]
+            dofs = [nd * s + c for nd in nodes for c in range(s)]
+            for i, di in enumerate(dofs):
+                for j, dj in enumerate(dofs):
+                    rows.append(di), cols.append(dj), vals.append(K[i, j])
+            for a, nd in enumerate(nodes):
+                for q in range(4):
+                    xi, eta = g[q & 1], g[(q >> 1) & 1]
+                    N = (xi if a & 1 else 1 - xi) * (eta if a & 2 else 1 - eta)
+                    for c in range(s):
+                        fv = 1.0 if fq is None else fq[c * NE * NE * 4 + ge + q]
+                        f[nd * s + c] += N * fv * hf * hf * 0.25
+    A = sp.csr_matrix((vals, (rows, cols)), shape=(NEp * NEp * s, NEp * NEp * s))
+    ix, iy = np.meshgrid(np.arange(NEp), np.arange(NEp))
+    interior = ((ix > 0) & (ix < NE) & (iy > 0) & (iy < NE)).ravel()
+    idx = np.nonzero(np.repeat(interior, s))[0]
+    return A[idx][:, idx].tocsc(), f[idx], idx
+
+
+def test_fem_rhs_matches_example_golden(so):
+    """'fem rhs l2 norm = 0.109375' of tests/Poisson_LOD_Example.output (H=1/4, n=2, f == 1) from
+    the device load-vector kernel, and a non-constant f against the numpy quadrature."""
+    torch, dev = _torch()
+    cfg, g = _mk(so, nref=2, n_sub=2, oversampling=1, stabilize=0)
+    NEp = g.NE + 1
+    rhs = torch.zeros(NEp * NEp, dtype=torch.float64, device=dev)
+    g.fem_rhs(None, rhs.data_ptr())
+    torch.cuda.synchronize()
+    assert abs(float(torch.linalg.norm(rhs)) - 0.109375) < 1e-15
+    r = rhs.cpu().numpy().reshape(NEp, NEp)
+    assert np.all(r[0] == 0) and np.all(r[-1] == 0) and np.all(r[:, 0] == 0) and np.all(r[:, -1] == 0)
+    rng = np.random.default_rng(3)
+    fq = rng.uniform(-1.0, 2.0, g.NE * g.NE * 4)
+    g.fem_rhs(torch.from_numpy(fq).to(dev).data_ptr(), rhs.data_ptr())
+    torch.cuda.synchronize()
+    _, fref, idx = _fem_reference(g.NE, 1, [np.ones(g.NE * g.NE * 4)], fq)
+    assert np.abs(rhs.cpu().numpy()[idx] - fref).max() <= 1e-15
+
+
+@pytest.mark.parametrize("kw,dist", [(dict(nref=3, n_sub=4, oversampling=1, spacedim=1), "D100"),
+                                     (dict(nref=3, n_sub=4, oversampling=1, spacedim=1), "D1e4"),
+                                     (dict(nref=2, n_sub=4, oversampling=1, spacedim=2), "D100")])
+def test_fem_solve_matches_sparse_direct(so, kw, dist):
+    """Matrix-free Jacobi-CG on the device stencil planes against scipy's sparse direct solve of the
+    same fine problem (independent assembly from oracle/slod_numpy.element_matrix)."""
+    import scipy.sparse.linalg as spl
+    torch, dev = _torch()
+    cfg, g = _mk(so, stabilize=1, **kw)
+    s = kw["spacedim"]
+    fields = make_fields(so, cfg, dist)
+    _upload(g, fields)
+    NEp = g.NE + 1
+    rhs = torch.zeros(NEp * NEp * s, dtype=torch.float64, device=dev)
+    u = torch.zeros_like(rhs)
+    g.fem_rhs(None, rhs.data_ptr())
+    it, res = g.fem_solve(rhs.data_ptr(), u.data_ptr(), 1e-13, 50000)
+    assert 0 < it < 50000 and res <= 1e-12
+    A, f, idx = _fem_reference(g.NE, s, fields)
+    uref = spl.spsolve(A, f)
+    uh = u.cpu().numpy()
+    assert np.abs(uh[idx] - uref).max() <= 1e-8 * np.abs(uref).max()
+    mask = np.ones(uh.size, bool)
+    mask[idx] = False
+    assert np.all(uh[mask] == 0.0)
+
+
+def test_lod_solution_converges_to_fem_with_oversampling(so):
+    """compare_lod_with_fem (LOD.cc:1240-1378) in one number: the reconstructed SLOD solution against
+    the fine FEM solution of the same rough coefficient; the error drops with the oversampling."""
+    torch, dev = _torch()
+    errs = []
+    for ell in (1, 2):
+        cfg, g = _mk(so, nref=3, n_sub=4, oversampling=ell, stabilize=1)
+        fields = make_fields(so, cfg, "D100")
+        _upload(g, fields)
+        ids = np.arange(g.num_patches, dtype=np.uint32)
+        plan = g.plan(ids)
+        stride = plan.stride
+        b = torch.zeros(len(ids) * stride, dtype=torch.float64, device=dev)
+        q = torch.zeros_like(b)
+        plan.execute(b.data_ptr(), q.data_ptr())
+        plan.status()
+        NEp = g.NE + 1
+        f = torch.zeros(NEp * NEp, dtype=torch.float64, device=dev)
+        g.fem_rhs(None, f.data_ptr())
+        ufem = torch.zeros_like(f)
+        it, res = g.fem_solve(f.data_ptr(), ufem.data_ptr(), 1e-12, 50000)
+        assert res <= 1e-11
+        values, cols = _lod_matrix(g, b, q, stride, 1)
+        rhs = torch.zeros(g.num_patches, dtype=torch.float64, device=dev)
+        g.lod_rhs(ids, b.data_ptr(), stride, f.data_ptr(), rhs.data_ptr())
+        uH = torch.zeros_like(rhs)
+        g.lod_solve(values.data_ptr(), cols.data_ptr(), rhs.data_ptr(), uH.data_ptr(), 1e-13, 5000)
+        ulod = torch.zeros_like(f)
+        g.lod_reconstruct(b.data_ptr(), stride, uH.data_ptr(), ulod.data_ptr())
+        torch.cuda.synchronize()
+        errs.append(float(torch.linalg.norm(ulod - ufem) / torch.linalg.norm(ufem)))
+    assert errs[1] < errs[0] and errs[1] < 2e-2, errs
