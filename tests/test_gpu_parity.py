@@ -81,10 +81,12 @@ def test_small_config_all_patches(so, stabilize, dist):
 
 
 @pytest.mark.parametrize("stabilize", [0, 1])
-def test_c1_all_patches(so, stabilize):
-    """BASELINE config C1: H=1/8, n=4, l=1, 64 patches."""
+@pytest.mark.parametrize("dist", ["const", "D100", "D1e4"])
+def test_c1_all_patches(so, stabilize, dist):
+    """BASELINE config C1: H=1/8, n=4, l=1, 64 patches (BASELINE quotes it with a constant
+    coefficient; the rough fields are the harder case)."""
     cfg, g = _mk(so, nref=3, n_sub=4, oversampling=1, stabilize=stabilize)
-    fields = make_fields(so, cfg, "D100")
+    fields = make_fields(so, cfg, dist)
     _upload(g, fields)
     ids = np.arange(g.num_patches)
     basis, premult, offs = g.compute_basis(ids)
