@@ -39,6 +39,7 @@ struct slod_plan
   size_t                     stride = 0, out_size = 0;
   size_t                     chunk = 0;
   double                    *ws_st = nullptr, *ws_v = nullptr, *ws_x = nullptr, *ws_m = nullptr;
+  double                    *ws_z = nullptr; // k_solve_tw: Z of the forward sweep (active column prefix per line)
   double                    *ws_x_alloc = nullptr; // ws_x sits `guard` doubles inside this allocation
   size_t                     guard = 0;
   size_t                     st_stride = 0, v_stride = 0, x_stride = 0;
@@ -241,6 +242,7 @@ namespace
     a.v_stride  = p->v_stride;
     a.m_max     = p->m_max;
     a.xs        = p->ws_x;
+    a.zs        = p->ws_z ? p->ws_z : p->ws_x;
     a.x_stride  = p->x_stride;
     a.nc_max    = p->nc_max;
     a.ms        = p->ws_m;
@@ -556,7 +558,8 @@ int slod_plan_create(slod_handle *h, const uint32_t *gids, size_t n, const uint6
   p->st_stride = (size_t)9 * s * s * p->nn_max;
   p->v_stride  = (size_t)p->L_max * p->choice.v_line_pad * p->choice.v_line_pad;
   p->x_stride  = (size_t)p->L_max * p->m_max * p->nc_max;
-  const size_t per_patch = (p->st_stride + p->v_stride + p->x_stride) * sizeof(double);
+  const bool   own_z = p->choice.kind == SLOD_K_TW;
+  const size_t per_patch = (p->st_stride + p->v_stride + (own_z ? 2 : 1) * p->x_stride) * sizeof(double);
   size_t       budget_mb = 24 * 1024;
   if (const char *env = std::getenv("SLOD_WORKSPACE_MB"))
     budget_mb = (size_t)std::max(64L, std::atol(env));
@@ -575,6 +578,11 @@ int slod_plan_create(slod_handle *h, const uint32_t *gids, size_t n, const uint6
   ok       = ok && hipMalloc((void **)&p->ws_x_alloc, (p->chunk * p->x_stride + 2 * p->guard) * sizeof(double)) == hipSuccess;
   ok       = ok && hipMemset(p->ws_x_alloc, 0, (p->chunk * p->x_stride + 2 * p->guard) * sizeof(double)) == hipSuccess;
   p->ws_x  = p->ws_x_alloc ? p->ws_x_alloc + p->guard : nullptr;
+  if (own_z)
+    {
+      ok = ok && hipMalloc((void **)&p->ws_z, (p->chunk * p->x_stride + p->guard) * sizeof(double)) == hipSuccess;
+      ok = ok && hipMemset(p->ws_z, 0, (p->chunk * p->x_stride + p->guard) * sizeof(double)) == hipSuccess;
+    }
   ok       = ok && hipMalloc((void **)&p->ws_m, p->chunk * (size_t)p->nc_max * p->nc_max * sizeof(double)) == hipSuccess;
   ok       = ok && hipMalloc((void **)&p->d_status, sizeof(int32_t)) == hipSuccess;
   ok       = ok && hipMalloc((void **)&p->d_pdiag, n * (size_t)s * sizeof(SlodPatchDiag)) == hipSuccess;
@@ -641,6 +649,8 @@ void slod_plan_destroy(slod_plan *p)
     (void)hipFree(p->ws_v);
   if (p->ws_x_alloc)
     (void)hipFree(p->ws_x_alloc);
+  if (p->ws_z)
+    (void)hipFree(p->ws_z);
   if (p->ws_m)
     (void)hipFree(p->ws_m);
   if (p->d_status)

@@ -71,6 +71,7 @@ struct SlodKernelArgs
   size_t  v_stride;
   int32_t m_max;
   double *xs;
+  double *zs;       // k_solve_tw: Z of the forward sweep (same strides as xs); other kernels keep Z in xs
   size_t  x_stride;
   int32_t nc_max;
   double *ms;       // per patch M = P^T A^-1 P / H^2 accumulated by k_solve_ws (nc_max^2 doubles)

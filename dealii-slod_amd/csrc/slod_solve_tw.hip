@@ -43,10 +43,18 @@ namespace
     auto    Bbuf = [&](double *base, int stp) { return base + ((stp + 3) % 3) * bsz; };
     double *ocb  = smem + (1 - chain) * chsz; // the other chain's block
     int    *colk = reinterpret_cast<int *>(smem + 2 * chsz); // [2][nc_max]
+    // Columns of P^T are zero until the sweep reaches their coarse cell, and so are the columns of
+    // Z: each chain numbers the columns by the step at which they become active (perm: chain order
+    // -> column, inv: column -> chain order, act: first active step, by chain order) and computes,
+    // stores and reads back only the active prefix.
+    int *perm = colk + 2 * A.nc_max + chain * 3 * A.nc_max, *inv = perm + A.nc_max, *act = inv + A.nc_max;
+    int *operm = colk + 2 * A.nc_max + (1 - chain) * 3 * A.nc_max, *oinv = operm + A.nc_max, *oact = oinv + A.nc_max;
+    (void)operm;
 
     const double *st    = A.st + (size_t)blockIdx.x * A.st_stride;
     double       *vg    = A.vinv + (size_t)blockIdx.x * A.v_stride;
-    double       *xg    = A.xs + (size_t)blockIdx.x * A.x_stride;
+    double       *xg    = A.xs + (size_t)blockIdx.x * A.x_stride; // X, column order of P^T
+    double       *zg    = A.zs + (size_t)blockIdx.x * A.x_stride; // Z, each chain's own column order
     const size_t  vline = (size_t)MP * MP, xline = (size_t)mm * ncg;
 
     const int mid = L / 2;
@@ -85,6 +93,29 @@ namespace
         colk[A.nc_max + c] = ky;
       }
     __syncthreads();
+    {
+      // first active step of a column: the sweep (line index + 1 = node row) reaches its coarse cell
+      auto first_step = [&](int ch, int c) {
+        const int kq = tr ? colk[c] : colk[A.nc_max + c];
+        const int a  = ch == 0 ? kq * n - 1 : L - (kq + 1) * n;
+        return a > 0 ? a : 0;
+      };
+      for (int idx = tid; idx < 2 * nc; idx += 256)
+        {
+          const int ch = idx / nc, c = idx - ch * nc, a = first_step(ch, c);
+          int       rank = 0;
+          for (int c2 = 0; c2 < nc; ++c2)
+            {
+              const int a2 = first_step(ch, c2);
+              rank += (a2 < a || (a2 == a && c2 < c)) ? 1 : 0;
+            }
+          int *pp = colk + 2 * A.nc_max + ch * 3 * A.nc_max;
+          pp[rank]                = c;
+          pp[A.nc_max + c]        = rank;
+          pp[2 * A.nc_max + rank] = a;
+        }
+      // (visible after the barrier that ends the band prologue below)
+    }
     // write the (zero padded) bands of `line`: T (within the line; zero band if !with_T) and the
     // coupling line -> line + dl of this chain; t0/nt = caller's thread slice
     auto put_bands = [&](int line, double *Tdst, bool with_T, double *Bdst, int t0, int nt) __attribute__((always_inline)) {
@@ -292,24 +323,30 @@ namespace
         // Each lane owns column r = lane&31 (+32 ...) and one half of the rows; it walks down its
         // rows with a sliding window of Z(prev)[p][r], p = i-W..i+W: one coalesced workspace load
         // per row instead of 2W+1 gathers, and the loads do not depend on the arithmetic.
-        auto build_R = [&](int line, const double *Bprev, const double *zprev, bool with_F, bool add) __attribute__((always_inline)) {
+        // ncols columns of Rb; cmap: column of P^T of Rb column r (nullptr: r); zmap: column of
+        // zprev that holds it (nullptr: r), valid only if that column was active at step tlim of the
+        // chain that wrote it (zact, by zprev column)
+        auto build_R = [&](int line, const double *Bprev, const double *zprev, int zstride, bool with_F, bool add, int ncols,
+                           const int *cmap, const int *zmap, const int *zact, int tlim) __attribute__((always_inline)) {
           if (SLOD_DG(A, 2))
             return;
           const int half = lane >> 5, i_lo = half ? (m + 1) / 2 : 0, i_hi = half ? m : (m + 1) / 2;
-          for (int r = lane & 31; r < nc; r += 32)
+          for (int r = lane & 31; r < ncols; r += 32)
             {
-              const int kxn = colk[r] * n, kyn = colk[A.nc_max + r] * n;
-              double    win[BW];
+              const int  c = cmap ? cmap[r] : r, zc = zmap ? zmap[r] : r;
+              const bool zok = zprev && zact[zc] <= tlim;
+              const int  kxn = colk[c] * n, kyn = colk[A.nc_max + c] * n;
+              double     win[BW];
 #pragma unroll
               for (int e = 0; e < BW; ++e)
                 {
                   const int p = i_lo + e - W;
-                  win[e]      = (zprev && p >= 0 && p < m) ? zprev[p * ncg + r] : 0.0;
+                  win[e]      = (zok && p >= 0 && p < m) ? zprev[p * zstride + zc] : 0.0;
                 }
               for (int i = i_lo; i < i_hi; ++i)
                 {
                   const int pn = i + 1 + W; // row entering the window for the next i
-                  const double znext = (zprev && pn < m) ? zprev[pn * ncg + r] : 0.0;
+                  const double znext = (zok && pn < m) ? zprev[pn * zstride + zc] : 0.0;
                   double       v     = add ? Rb[i * ncs + r] : 0.0;
                   if (with_F)
                     {
@@ -321,7 +358,7 @@ namespace
                           if (S == 1)
                             v += A.scale * (((jx == 0 || jx == n) ? 1.0 : 2.0) * ((jy == 0 || jy == n) ? 1.0 : 2.0));
                           else
-                            v += A.scale * pt_weight<S>(d, n, A.quirk, ix, iy, comp, r);
+                            v += A.scale * pt_weight<S>(d, n, A.quirk, ix, iy, comp, c);
                         }
                     }
 #pragma unroll
@@ -335,13 +372,14 @@ namespace
                 }
             }
         };
-        const int tiles_i = (m + 15) >> 4, tiles_j = (nc + 15) >> 4;
-        // Z(line) = V(line) Rb -> workspace; A operand straight from the workspace (rows clamped)
-        auto gemm_Z = [&](int line) __attribute__((always_inline)) {
+        const int tiles_i = (m + 15) >> 4;
+        // (first ncols columns of) Z(line) = V(line) Rb -> workspace row xl; A operand straight from
+        // the workspace (rows clamped)
+        auto gemm_Z = [&](int line, int ncols, double *xl, int xstride) __attribute__((always_inline)) {
           if (SLOD_DG(A, 8))
             return;
           const double *vl = vg + (size_t)line * vline;
-          double       *xl = xg + (size_t)line * xline;
+          const int     tiles_j = (ncols + 15) >> 4;
           // one row tile of A (16 x MP of V, from the workspace) feeds all column tiles; the
           // next row tile is fetched while the MFMAs of the current one run
           double av[MP / 4], an[MP / 4];
@@ -373,10 +411,10 @@ namespace
                   for (int r = 0; r < 4; ++r)
                     {
                       const int row = 16 * ti + (lane >> 4) + 4 * r, col = 16 * tj + (lane & 15);
-                      if (row < m && col < nc)
-                        xl[row * ncg + col] = acc0[r];
-                      if (two && row < m && col + 16 < nc)
-                        xl[row * ncg + col + 16] = acc1[r];
+                      if (row < m && col < ncols)
+                        xl[row * xstride + col] = acc0[r];
+                      if (two && row < m && col + 16 < ncols)
+                        xl[row * xstride + col + 16] = acc1[r];
                     }
                 }
 #pragma unroll
@@ -384,33 +422,34 @@ namespace
                 av[kk] = an[kk];
             }
         };
+        int na = 0; // active columns (chain order) at the step being processed
+        // RHS block and Z of step tl: active columns only; Z(prev) of a column that became active
+        // at this very step was never written (it is zero)
+        // A line of Z is stored compactly: [m][na(line)], so only whole cache lines of active data move
+        auto fwd_step = [&](int tl) __attribute__((always_inline)) {
+          const int na_prev = na;
+          while (na < nc && act[na] <= tl)
+            ++na;
+          const int line = line_of(chain, tl);
+          build_R(line, Bbuf(Bc0, tl - 1), tl > 0 ? zg + (size_t)line_of(chain, tl - 1) * xline : nullptr, na_prev, true,
+                  false, na, perm, nullptr, act, tl - 1);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          gemm_Z(line, na, zg + (size_t)line * xline, na);
+        };
         for (int t = 0; t < nstp; ++t)
           {
+            // line(t-1): its V became visible at A_{t-1}; the coupling line(t-2) -> line(t-1) is the
+            // B band of step t-2
             if (t > 0 && t - 1 < nmy)
-              {
-                // RHS block and Z of line(t-1): its V became visible at A_{t-1}; the coupling
-                // line(t-2) -> line(t-1) is the B band of step t-2
-                const int line = line_of(chain, t - 1);
-                build_R(line, Bbuf(Bc0, t - 2), t > 1 ? xg + (size_t)line_of(chain, t - 2) * xline : nullptr, true,
-                        false);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                gemm_Z(line);
-              }
+              fwd_step(t - 1);
             if (t > 0 && !(SLOD_DG(A, 32)))
               put_step(t + 1, lane, 64); // bands the GJ wave needs after its next sweep
             __syncthreads(); // A_t
           }
         // R/Z of the last step (the shorter chain of an even L already did its last line in the loop)
         if (nmy == nstp && nmy > 0)
-          {
-            const int t = nstp;
-            const int line = line_of(chain, t - 1);
-            build_R(line, Bbuf(Bc0, t - 2), t > 1 ? xg + (size_t)line_of(chain, t - 2) * xline : nullptr, true, false);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            gemm_Z(line);
-          }
+          fwd_step(nstp - 1);
         __syncthreads(); // M1 (also: both chains' last Z are in the workspace)
         __syncthreads(); // M2: V_mid is in the workspace
         if (chain == 0)
@@ -419,13 +458,20 @@ namespace
             const double *B0 = Bbuf(Bc0, n0 - 1);
             double       *ob = ocb + MP * ncs + MP + 3 * bsz; // other chain's Bc0
             const double *B1 = Bbuf(ob, n1 - 1);
-            build_R(mid, B0, n0 > 0 ? xg + (size_t)(mid - 1) * xline : nullptr, true, false);
+            // all columns, in the order of P^T; Z(mid-1) / Z(mid+1) through each chain's numbering
+            int na0 = 0, na1 = 0; // row strides of the two neighbouring lines of Z
+            while (na0 < nc && act[na0] <= n0 - 1)
+              ++na0;
+            while (na1 < nc && oact[na1] <= n1 - 1)
+              ++na1;
+            build_R(mid, B0, n0 > 0 ? zg + (size_t)(mid - 1) * xline : nullptr, na0, true, false, nc, nullptr, inv, act,
+                    n0 - 1);
             __builtin_amdgcn_wave_barrier();
             if (n1 > 0)
-              build_R(mid, B1, xg + (size_t)(mid + 1) * xline, false, true);
+              build_R(mid, B1, zg + (size_t)(mid + 1) * xline, na1, false, true, nc, nullptr, oinv, oact, n1 - 1);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            gemm_Z(mid); // X_mid
+            gemm_Z(mid, nc, xg + (size_t)mid * xline, ncg); // X_mid
           }
         __syncthreads(); // M3
       }
@@ -467,8 +513,11 @@ namespace
           fetch_B(line_of(chain, nmy - 1)); // shorter chain: its first active step is nmy-1
           store_B(((nmy - 1) & 1) ? Bc1 : Bc0);
         }
+      int nab = nc; // active columns = row stride of the line of Z being read (steps run downwards)
       for (int t = tstart; t >= 0; --t)
         {
+          while (nab > 0 && act[nab - 1] > t)
+            --nab;
           const bool    active = t < nmy;
           const int     line = line_of(chain, t), prev = line_of(chain, t + 1); // prev: solved before (mid first)
           const double *Bn = (t & 1) ? Bc1 : Bc0;
@@ -515,12 +564,17 @@ namespace
                   const int ti = tt / tiles_j, tj = tt - ti * tiles_j;
                   const int col = 16 * tj + (lane & 15);
                   const int arow = min(16 * ti + (lane & 15), MP - 1);
-                  double    zl[4];
+                  // Z(line) in the chain's column numbering; never written where the column was not
+                  // yet active in the forward sweep (zero there)
+                  const double *zrow = zg + (size_t)line * xline;
+                  const int     zc   = col < nc ? inv[col] : nc;
+                  const bool    zok  = zc < nab; // the chain order is sorted by the first active step
+                  double        zl[4];
 #pragma unroll
                   for (int r = 0; r < 4; ++r)
                     {
                       const int row = 16 * ti + (lane >> 4) + 4 * r;
-                      zl[r]         = (row < m && col < nc) ? xl[row * ncg + col] : 0.0;
+                      zl[r]         = (row < m && zok) ? zrow[row * nab + zc] : 0.0;
                     }
                   double4_t     acc = {0.0, 0.0, 0.0, 0.0};
                   const double *ap  = vl + arow * MP + (lane >> 4);
@@ -571,7 +625,7 @@ size_t slod_solve_tw_lds_bytes(int S, int m_max, int nc_max)
   const int    ncs = (nc_max + 1) & ~1, bsz = ((MP + 2 * W) * (BW + 1) + 1) & ~1;
   (void)m_max;
   const size_t chsz = (size_t)MP * ncs + MP + 6 * (size_t)bsz;
-  return ((2 * chsz * sizeof(double) + 2 * (size_t)nc_max * sizeof(int)) + 15) & ~(size_t)15;
+  return ((2 * chsz * sizeof(double) + 8 * (size_t)nc_max * sizeof(int)) + 15) & ~(size_t)15; // colk + perm/inv/act
 }
 
 template <int T, int S>
