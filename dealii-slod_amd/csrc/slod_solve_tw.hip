@@ -55,7 +55,31 @@ namespace
     double       *vg    = A.vinv + (size_t)blockIdx.x * A.v_stride;
     double       *xg    = A.xs + (size_t)blockIdx.x * A.x_stride; // X, column order of P^T
     double       *zg    = A.zs + (size_t)blockIdx.x * A.x_stride; // Z, each chain's own column order
-    const size_t  vline = (size_t)MP * MP, xline = (size_t)mm * ncg;
+    // V of a line is symmetric: only the 36 lane tiles on or above the diagonal of the 8 x 8 lane
+    // grid are stored, tile (a, b >= a) as a contiguous T x T block at index a*8 - a(a-1)/2 + b - a
+    const size_t  vline = (size_t)36 * T * T, xline = (size_t)mm * ncg;
+    auto          vtile = [](int a, int b) { return a * 8 - (a * (a - 1)) / 2 + (b - a); };
+    // MFMA A operand from that storage: lane (r = lane & 15, kq = lane >> 4) of step kk = g T + kr
+    // takes V[16 ti + r][k], k = T (kq + 4 g) + kr -- the K index is permuted so that the lane tile
+    // column of k is a per-lane constant plus 4 g and kr is a compile-time constant; the B operand
+    // uses the same k (row k of the LDS block).  Tiles below the diagonal are read transposed.
+    auto load_A = [&](const double *vl, int ti, double (&dst)[MP / 4]) __attribute__((always_inline)) {
+      const int row = min(16 * ti + (lane & 15), MP - 1);
+      const int rt = row / T, rr = row - rt * T, kq = lane >> 4;
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+        {
+          const int     kt = kq + 4 * g;
+          const bool    up = rt <= kt;
+          const double *base = vl + vtile(up ? rt : kt, up ? kt : rt) * (T * T) + (up ? rr * T : rr);
+          const int     step = up ? 1 : T;
+#pragma unroll
+          for (int kr = 0; kr < T; ++kr)
+            dst[g * T + kr] = base[kr * step];
+        }
+    };
+    // row of the B operand (LDS block) of step kk for this lane: T (kq + 4 g) + kr
+    auto brow = [&](int kk) { return T * ((lane >> 4) + 4 * (kk / T)) + kk % T; };
 
     const int mid = L / 2;
     const int n0 = mid, n1 = L - 1 - mid, nstp = n0 > n1 ? n0 : n1;
@@ -263,11 +287,15 @@ namespace
         };
         // tile <-> global [MP][MP] block (V lines, and the meeting-line contribution of chain 1)
         auto store_tile = [&](double *dst, double sign) __attribute__((always_inline)) {
+          if (gy <= gx)
+            {
+              double *tp = dst + vtile(gy, gx) * (T * T);
 #pragma unroll
-          for (int ta = 0; ta < T; ++ta)
+              for (int ta = 0; ta < T; ++ta)
 #pragma unroll
-            for (int tb = 0; tb < T; ++tb)
-              dst[(T * gy + ta) * MP + T * gx + tb] = sign * a[ta][tb];
+                for (int tb = 0; tb < T; ++tb)
+                  tp[ta * T + tb] = sign * a[ta][tb];
+            }
         };
         // a = T of the chain's first line (chain 1 without lines contributes nothing)
 #pragma unroll
@@ -301,12 +329,13 @@ namespace
         __syncthreads(); // M1: chain 1's contribution is in the workspace
         if (chain == 0)
           {
-            const double *w1 = vg + (size_t)mid * vline;
+            const bool    up = gy <= gx;
+            const double *w1 = vg + (size_t)mid * vline + vtile(up ? gy : gx, up ? gx : gy) * (T * T);
 #pragma unroll
             for (int ta = 0; ta < T; ++ta)
 #pragma unroll
               for (int tb = 0; tb < T; ++tb)
-                a[ta][tb] += w1[(T * gy + ta) * MP + T * gx + tb];
+                a[ta][tb] += w1[up ? ta * T + tb : tb * T + ta];
             sweep();
             store_tile(vg + (size_t)mid * vline, -1.0);
           }
@@ -383,29 +412,23 @@ namespace
           // one row tile of A (16 x MP of V, from the workspace) feeds all column tiles; the
           // next row tile is fetched while the MFMAs of the current one run
           double av[MP / 4], an[MP / 4];
-          auto   load_A = [&](int ti, double (&dst)[MP / 4]) __attribute__((always_inline)) {
-            const double *ap = vl + min(16 * ti + (lane & 15), MP - 1) * MP + (lane >> 4);
-#pragma unroll
-            for (int kk = 0; kk < MP / 4; ++kk)
-              dst[kk] = ap[4 * kk];
-          };
-          load_A(0, av);
+          load_A(vl, 0, av);
           for (int ti = 0; ti < tiles_i; ++ti)
             {
               if (ti + 1 < tiles_i)
-                load_A(ti + 1, an);
+                load_A(vl, ti + 1, an);
               for (int tj = 0; tj < tiles_j; tj += 2)
                 {
                   // two independent accumulators (column tiles tj, tj+1) back to back
                   double4_t     acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-                  const double *bp  = Rb + (lane >> 4) * ncs + 16 * tj + (lane & 15);
+                  const double *bp  = Rb + 16 * tj + (lane & 15);
                   const bool    two = tj + 1 < tiles_j;
 #pragma unroll
                   for (int kk = 0; kk < MP / 4; ++kk)
                     {
-                      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bp[4 * kk * ncs], acc0, 0, 0, 0);
+                      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bp[brow(kk) * ncs], acc0, 0, 0, 0);
                       if (two)
-                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bp[4 * kk * ncs + 16], acc1, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bp[brow(kk) * ncs + 16], acc1, 0, 0, 0);
                     }
 #pragma unroll
                   for (int r = 0; r < 4; ++r)
@@ -563,7 +586,6 @@ namespace
                 {
                   const int ti = tt / tiles_j, tj = tt - ti * tiles_j;
                   const int col = 16 * tj + (lane & 15);
-                  const int arow = min(16 * ti + (lane & 15), MP - 1);
                   // Z(line) in the chain's column numbering; never written where the column was not
                   // yet active in the forward sweep (zero there)
                   const double *zrow = zg + (size_t)line * xline;
@@ -577,15 +599,12 @@ namespace
                       zl[r]         = (row < m && zok) ? zrow[row * nab + zc] : 0.0;
                     }
                   double4_t     acc = {0.0, 0.0, 0.0, 0.0};
-                  const double *ap  = vl + arow * MP + (lane >> 4);
-                  const double *bp  = Rb + (lane >> 4) * ncs + col;
+                  const double *bp  = Rb + col;
                   double        av[MP / 4];
+                  load_A(vl, ti, av);
 #pragma unroll
                   for (int kk = 0; kk < MP / 4; ++kk)
-                    av[kk] = ap[4 * kk];
-#pragma unroll
-                  for (int kk = 0; kk < MP / 4; ++kk)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bp[4 * kk * ncs], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bp[brow(kk) * ncs], acc, 0, 0, 0);
 #pragma unroll
                   for (int r = 0; r < 4; ++r)
                     {
