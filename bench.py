@@ -260,7 +260,7 @@ def main():
             # same 78.6 TFLOP/s): "mfma" names that peak; what actually limits the kernel today is
             # the instruction issue / dependent-chain latency of its Gauss-Jordan waves
             "roofline": {"bound": "mfma",
-                         "limiter": "forward sweep: dependent-chain latency of the Gauss-Jordan waves; backward sweep: HBM rate (V and Z streamed from the workspace at ~3.8 TB/s); DESIGN section 6",
+                         "limiter": "dependent chains per patch: Gauss-Jordan pivots in the forward sweep, exposed workspace-load latencies in the backward sweep (DESIGN section 6)",
                          "kernel": "k_solve_%s" % os.environ.get("SLOD_SOLVE", "tw") + (" (stencil assembly and selection stage fused in)" if ks[2] < 0.05 * ks[1] and ks[0] < 0.05 * ks[1] else (" (selection stage fused in)" if ks[2] < 0.05 * ks[1] else "")),
                          "achieved": achieved_tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / PEAK_FP64_TFLOPS, "traffic": traffic,
