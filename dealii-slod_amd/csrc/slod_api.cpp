@@ -546,7 +546,8 @@ int slod_plan_create(slod_handle *h, const uint32_t *gids, size_t n, const uint6
   (void)nb_min_slod;
   // k_select reduces the boundary-trace matrix by QR in row chunks (TSQR): the LDS buffer
   // holds nb_buf rows, at least nc_max + 16 so every chunk brings new rows
-  p->nb_buf = std::min(p->nb_max, std::max(96, p->nc_max + 16));
+  // (vector problems: 80 rows keep k_select<2> under 80 KB of LDS, i.e. two workgroups per CU)
+  p->nb_buf = std::min(p->nb_max, std::max(s == 1 ? 96 : 80, p->nc_max + 16));
   // the kernel family, its LDS size and the fused stages are fixed here, once (the same function
   // the launch uses): a plan that no kernel can run is rejected now, not at execute
   if (!slod_choose_solver(s, p->m_max, p->nc_max, p->nb_buf, p->nf_max, n, slod_read_tuning(), &p->choice))

@@ -4,7 +4,7 @@
 namespace
 {
   template <int S>
-  __global__ __launch_bounds__(256) void k_select(const SlodKernelArgs A, int nb_max, int nf_max)
+  __global__ __launch_bounds__(256, S == 1 ? 1 : 2) void k_select(const SlodKernelArgs A, int nb_max, int nf_max)
   {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     select_patch<S>(A, nb_max, nf_max, blockIdx.x, smem);
