@@ -177,6 +177,19 @@ namespace
         __builtin_amdgcn_s_setprio(3);
         const int gy = lane >> 3, gx = lane & 7;
         double    a[T][T];
+        // neighbour lane in the same lane-grid row through DPP (row_shr:1 / row_shl:1, no LDS trip):
+        // the lanes at the ends of an 8-lane grid row receive a foreign (finite) value that only
+        // ever meets a zero band entry
+        auto dpp_from_prev = [](double x) {
+          const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x111, 0xf, 0xf, true);
+          const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x111, 0xf, 0xf, true);
+          return __hiloint2double(hi, lo);
+        };
+        auto dpp_from_next = [](double x) {
+          const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x101, 0xf, 0xf, true);
+          const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x101, 0xf, 0xf, true);
+          return __hiloint2double(hi, lo);
+        };
         auto next_S = [&](const double *Tsrc, const double *Bl) __attribute__((always_inline)) {
           const double *cbp = Bl + (T * gx) * BWP + 2 * W;
 #pragma unroll
@@ -186,8 +199,8 @@ namespace
 #pragma unroll
               for (int w = 0; w < W; ++w)
                 {
-                  ext[w]         = -__shfl(a[ta][T - W + w], lane - 1, 64);
-                  ext[W + T + w] = -__shfl(a[ta][w], lane + 1, 64);
+                  ext[w]         = W == 1 ? -dpp_from_prev(a[ta][T - W + w]) : -__shfl(a[ta][T - W + w], lane - 1, 64);
+                  ext[W + T + w] = W == 1 ? -dpp_from_next(a[ta][w]) : -__shfl(a[ta][w], lane + 1, 64);
                 }
 #pragma unroll
               for (int tb = 0; tb < T; ++tb)
@@ -204,6 +217,19 @@ namespace
               __builtin_amdgcn_sched_barrier(0);
             }
           const double *dbp = Bl + (T * gy) * BWP + 2 * W;
+          // rows of the lane-grid neighbours above and below, all columns in one batch
+          double up[T][W], dn[T][W];
+          if (W == 1) // (wider bands: too many registers, the exchange stays inside the column loop)
+            {
+#pragma unroll
+              for (int tb = 0; tb < T; ++tb)
+#pragma unroll
+                for (int w = 0; w < W; ++w)
+                  {
+                    up[tb][w] = __shfl(a[T - W + w][tb], lane - 8, 64);
+                    dn[tb][w] = __shfl(a[w][tb], lane + 8, 64);
+                  }
+            }
 #pragma unroll
           for (int tb = 0; tb < T; ++tb)
             {
@@ -212,8 +238,8 @@ namespace
 #pragma unroll
               for (int w = 0; w < W; ++w)
                 {
-                  ext[w]         = __shfl(a[T - W + w][tb], lane - 8, 64);
-                  ext[W + T + w] = __shfl(a[w][tb], lane + 8, 64);
+                  ext[w]         = W == 1 ? up[tb][w] : __shfl(a[T - W + w][tb], lane - 8, 64);
+                  ext[W + T + w] = W == 1 ? dn[tb][w] : __shfl(a[w][tb], lane + 8, 64);
                 }
 #pragma unroll
               for (int ta = 0; ta < T; ++ta)
