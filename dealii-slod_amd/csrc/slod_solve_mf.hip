@@ -80,10 +80,9 @@ namespace
     const int           wave  = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int           chain = wave & 1;
     const bool          is_gj = wave < 2;
-    const int           g = lane >> 4, c = lane & 15;
     const int           m = d.m, L = d.L, nc = d.n_c, n = A.n_sub;
     const int           mm = A.m_max, ncg = A.nc_max;
-    const int           nct = (nc + 15) >> 4, npass = (nct + 1) >> 1;
+    const int           nct = (nc + 15) >> 4;
     const bool          tr  = (d.flags & SLOD_F_TRANSPOSED) != 0;
     const int           npx = d.nx + 1;
 
