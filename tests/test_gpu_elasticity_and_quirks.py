@@ -350,3 +350,30 @@ def test_fused_and_split_selection_agree(so, monkeypatch):
     monkeypatch.setenv("SLOD_FUSE_ASSEMBLE", "0")
     b2, p2, _ = g.compute_basis(ids)
     assert np.array_equal(b2, b1) and np.array_equal(p2, p1)
+
+
+@pytest.mark.gpu
+def test_balanced_launch_order_is_transparent(so, monkeypatch):
+    """The plan launches the patches in a cost-balanced order (SLOD_BALANCE=0: the caller's order);
+    outputs, offsets and the per-patch diagnostics stay in the caller's order either way."""
+    cfg, g = _mk(so, nref=4, n_sub=4, oversampling=2, stabilize=1)
+    fields = make_fields(so, cfg, "D1e4")
+    _upload(g, fields)
+    ids = np.arange(g.num_patches - 1, -1, -1, dtype=np.uint32)[::2].copy()   # descending, every other patch
+    b1, p1, _ = g.compute_basis(ids)
+    plan = g.plan(ids)
+    import torch
+    dev = torch.device("cuda", 0)
+    tb = torch.zeros(len(ids) * plan.stride, dtype=torch.float64, device=dev)
+    tq = torch.zeros_like(tb)
+    plan.execute(tb.data_ptr(), tq.data_ptr())
+    plan.status()
+    d1 = [(d.path, d.n_cut, d.n_dropped) for d in plan.diagnostics()]
+    monkeypatch.setenv("SLOD_BALANCE", "0")
+    b0, p0, _ = g.compute_basis(ids)
+    plan0 = g.plan(ids)
+    plan0.execute(tb.data_ptr(), tq.data_ptr())
+    plan0.status()
+    d0 = [(d.path, d.n_cut, d.n_dropped) for d in plan0.diagnostics()]
+    assert np.array_equal(b0, b1) and np.array_equal(p0, p1)
+    assert d0 == d1 and len(set(d1)) > 1          # rim and full patches decide differently
