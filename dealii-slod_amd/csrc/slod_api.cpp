@@ -557,11 +557,19 @@ int slod_plan_create(slod_handle *h, const uint32_t *gids, size_t n, const uint6
     }
   p->nn_max    = (p->nn_max + 31) & ~31; // 256-byte aligned stencil planes
   p->st_stride = (size_t)9 * s * s * p->nn_max;
-  p->v_stride  = (size_t)p->L_max * p->choice.v_line_pad * p->choice.v_line_pad;
+  p->v_stride  = (size_t)p->L_max * p->choice.v_line_elems;
   p->x_stride  = (size_t)p->L_max * p->m_max * p->nc_max;
   const bool   own_z = p->choice.kind == SLOD_K_TW;
   const size_t per_patch = (p->st_stride + p->v_stride + (own_z ? 2 : 1) * p->x_stride) * sizeof(double);
-  size_t       budget_mb = 24 * 1024;
+  // Workspace budget: 24 GB, or 60 % of what is free on the device if that is more (an MI355X has
+  // 288 GB: big plans then run in few, long launches -- C3 in 3 chunks instead of 14, less idle
+  // tail per chunk); SLOD_WORKSPACE_MB overrides
+  size_t budget_mb = 24 * 1024;
+  {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+      budget_mb = std::max<size_t>(budget_mb, free_b / (1024 * 1024) * 6 / 10);
+  }
   if (const char *env = std::getenv("SLOD_WORKSPACE_MB"))
     budget_mb = (size_t)std::max(64L, std::atol(env));
   p->chunk = std::max<size_t>(1, std::min<size_t>(n, budget_mb * 1024 * 1024 / per_patch));

@@ -109,7 +109,8 @@ struct SlodSolveChoice
   int    kind = 0;
   size_t lds  = 0;
   int    fuse_select = 0, fuse_assemble = 0, m_fused = 0, twisted = 0, debug = 0;
-  int    v_line_pad = 0; // rows = columns of a stored V line in the workspace
+  int    v_line_pad = 0; // rows = columns of a V line as the kernel sees it
+  size_t v_line_elems = 0; // doubles per stored V line (k_solve_tw: the 36 upper lane tiles only)
 };
 SlodTuning slod_read_tuning();
 bool       slod_choose_solver(int S, int m_max, int nc_max, int nb_buf, int nf_max, size_t n_patches,

@@ -57,6 +57,7 @@ bool slod_choose_solver(int S, int m_max, int nc_max, int nb_buf, int nf_max, si
       c.kind          = SLOD_K_MF;
       c.lds           = slod_solve_mf_lds_bytes(S, m_max, nc_max);
       c.v_line_pad    = 16 * slod_solve_mf_tiles(S, m_max);
+      c.v_line_elems  = (size_t)c.v_line_pad * c.v_line_pad;
       c.fuse_assemble = (S == 1 && t.fuse_assemble) ? 1 : 0;
       c.fuse_select   = (S == 1 && t.fuse_select && lds_sel <= lds_max) ? 1 : 0;
       if (c.fuse_select && lds_sel > c.lds)
@@ -67,6 +68,7 @@ bool slod_choose_solver(int S, int m_max, int nc_max, int nb_buf, int nf_max, si
       c.kind          = SLOD_K_TW;
       c.lds           = slod_solve_tw_lds_bytes(S, m_max, nc_max);
       c.v_line_pad    = 8 * wt;
+      c.v_line_elems  = (size_t)36 * wt * wt; // symmetric: lane tiles on or above the diagonal
       c.fuse_assemble = (S == 1 && t.fuse_assemble) ? 1 : 0;
       // the selection stage runs in the same launch (scalar problems) while four workgroups
       // still fit a CU
@@ -80,6 +82,7 @@ bool slod_choose_solver(int S, int m_max, int nc_max, int nb_buf, int nf_max, si
       c.kind       = SLOD_K_WS;
       c.lds        = slod_solve_ws_lds_bytes(S, m_max, nc_max);
       c.v_line_pad = 8 * wt;
+      c.v_line_elems = (size_t)c.v_line_pad * c.v_line_pad;
       // fusing M = sum_l R_l^T Z_l into the helper waves saves the selection stage's re-read of X
       // but costs a fourth barrier per line; measured neutral on C2, so opt-in (SLOD_FUSE_M=1)
       c.m_fused = (t.fuse_m && nc_max * nc_max <= 192 * 4) ? 1 : 0;
@@ -97,6 +100,7 @@ bool slod_choose_solver(int S, int m_max, int nc_max, int nb_buf, int nf_max, si
       c.twisted    = tw;
       c.lds        = slod_solve_lds_bytes(S, m_max, nc_max, tw);
       c.v_line_pad = m_max;
+      c.v_line_elems = (size_t)m_max * m_max;
     }
   else
     return false;
