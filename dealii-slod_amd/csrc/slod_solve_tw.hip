@@ -199,8 +199,8 @@ namespace
 #pragma unroll
               for (int w = 0; w < W; ++w)
                 {
-                  ext[w]         = W == 1 ? -dpp_from_prev(a[ta][T - W + w]) : -__shfl(a[ta][T - W + w], lane - 1, 64);
-                  ext[W + T + w] = W == 1 ? -dpp_from_next(a[ta][w]) : -__shfl(a[ta][w], lane + 1, 64);
+                  ext[w]         = -dpp_from_prev(a[ta][T - W + w]);
+                  ext[W + T + w] = -dpp_from_next(a[ta][w]);
                 }
 #pragma unroll
               for (int tb = 0; tb < T; ++tb)
