@@ -7,7 +7,7 @@ namespace
   __global__ __launch_bounds__(256, S == 1 ? 1 : 2) void k_select(const SlodKernelArgs A, int nb_max, int nf_max)
   {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    select_patch<S>(A, nb_max, nf_max, blockIdx.x, smem);
+    select_patch<S, true>(A, nb_max, nf_max, blockIdx.x, smem);
   }
 } // namespace
 

@@ -19,7 +19,9 @@ namespace
   // singular values / right vectors as BD', u_j^T g = (R v_j).c) replays the loop literally.
   // One 256-thread workgroup, patch `patch` of the launch; `smem` = the workgroup's dynamic LDS
   // (slod_select_lds_bytes).  Called by k_select and, fused, at the end of k_solve_tw.
-  template <int S>
+  // OWN: the stage is a kernel of its own (k_select) and may spend registers on batched LDS loads;
+  // fused into a solve kernel it shares that kernel's tighter register budget
+  template <int S, bool OWN = false>
   __device__ __forceinline__ void select_patch(const SlodKernelArgs &A, const int nb_max, const int nf_max,
                                                const int patch, double *smem)
   {
@@ -603,31 +605,82 @@ namespace
                         const double alpha = (x0 >= 0.0) ? -sq : sq;
                         const double v0    = x0 - alpha;
                         const double beta  = fast_rcp(sigma - alpha * x0); // 2 / v^T v
-                        // apply H = I - beta v v^T to the trailing columns and to b0
-                        for (int t = grp; t < nn1 - k; t += 16)
+                        if constexpr (OWN)
                           {
-                            const int cj = (t == nn1 - k - 1) ? dsel : cix(k + 1 + t);
-                            double    sd = 0.0;
-                            for (int r = k + l16; r < rows; r += 16)
+                            // apply H = I - beta v v^T to the trailing columns and to b0.  The lane's rows
+                            // of the reflector and of a column are loaded in one batch each (the buffer
+                            // holds at most 16 NRL rows; unconditional, clamped loads): the dependent
+                            // chain is then arithmetic only, not one LDS round trip per row
+                            constexpr int NRL = 10;
+                            double        vr[NRL];
+    #pragma unroll
+                            for (int i = 0; i < NRL; ++i)
                               {
-                                const double vr = (r == k) ? v0 : BD[r * ncm + ck];
-                                sd              = fma(vr, BD[r * ncm + cj], sd);
+                                const int    r = k + l16 + 16 * i;
+                                const double x = BD[min(r, rows - 1) * ncm + ck];
+                                vr[i]          = (r < rows) ? ((r == k) ? v0 : x) : 0.0;
                               }
-                            sd = group16_sum(sd) * beta;
-                            double nxt = 0.0;
-                            for (int r = k + l16; r < rows; r += 16)
+                            for (int t = grp; t < nn1 - k; t += 16)
                               {
-                                const double vr = (r == k) ? v0 : BD[r * ncm + ck];
-                                const double nv = fma(-sd, vr, BD[r * ncm + cj]);
-                                BD[r * ncm + cj] = nv;
-                                if (r > k)
-                                  nxt = fma(nv, nv, nxt);
+                                const int cj = (t == nn1 - k - 1) ? dsel : cix(k + 1 + t);
+                                double    xj[NRL];
+    #pragma unroll
+                                for (int i = 0; i < NRL; ++i)
+                                  xj[i] = BD[min(k + l16 + 16 * i, rows - 1) * ncm + cj];
+                                double sd = 0.0;
+    #pragma unroll
+                                for (int i = 0; i < NRL; ++i)
+                                  sd = (k + l16 + 16 * i < rows) ? fma(vr[i], xj[i], sd) : sd;
+                                sd = group16_sum(sd) * beta;
+                                double nxt = 0.0;
+    #pragma unroll
+                                for (int i = 0; i < NRL; ++i)
+                                  {
+                                    const int r = k + l16 + 16 * i;
+                                    if (r < rows)
+                                      {
+                                        const double nv  = fma(-sd, vr[i], xj[i]);
+                                        BD[r * ncm + cj] = nv;
+                                        if (r > k)
+                                          nxt = fma(nv, nv, nxt);
+                                      }
+                                  }
+                                if (t == 0 && k + 1 < nn1) // cj is the next pivot column
+                                  {
+                                    nxt = group16_sum(nxt);
+                                    if (l16 == 0)
+                                      sig[(k + 1) & 1] = nxt;
+                                  }
                               }
-                            if (t == 0 && k + 1 < nn1) // cj is the next pivot column
+                          }
+                        else
+                          {
+                            // apply H = I - beta v v^T to the trailing columns and to b0
+                            for (int t = grp; t < nn1 - k; t += 16)
                               {
-                                nxt = group16_sum(nxt);
-                                if (l16 == 0)
-                                  sig[(k + 1) & 1] = nxt;
+                                const int cj = (t == nn1 - k - 1) ? dsel : cix(k + 1 + t);
+                                double    sd = 0.0;
+                                for (int r = k + l16; r < rows; r += 16)
+                                  {
+                                    const double vr = (r == k) ? v0 : BD[r * ncm + ck];
+                                    sd              = fma(vr, BD[r * ncm + cj], sd);
+                                  }
+                                sd = group16_sum(sd) * beta;
+                                double nxt = 0.0;
+                                for (int r = k + l16; r < rows; r += 16)
+                                  {
+                                    const double vr = (r == k) ? v0 : BD[r * ncm + ck];
+                                    const double nv = fma(-sd, vr, BD[r * ncm + cj]);
+                                    BD[r * ncm + cj] = nv;
+                                    if (r > k)
+                                      nxt = fma(nv, nv, nxt);
+                                  }
+                                if (t == 0 && k + 1 < nn1) // cj is the next pivot column
+                                  {
+                                    nxt = group16_sum(nxt);
+                                    if (l16 == 0)
+                                      sig[(k + 1) & 1] = nxt;
+                                  }
                               }
                           }
                         __syncthreads();
