@@ -293,10 +293,26 @@ def test_selection_decisions_match_oracle(so, kw, dist):
     print("%s %s: %d of %d patches replayed the truncation loop" % (kw, dist, n_path2, len(ids)))
 
 
+
+def _decisions(g, ids, offs):
+    """slod_plan_diagnostics of the same patches (plan path; outputs must equal the host-buffer path)"""
+    import torch
+    plan = g.plan(ids, offs)
+    dev = torch.device("cuda", 0)
+    b = torch.zeros(max(plan.output_size, 1), dtype=torch.float64, device=dev)
+    q = torch.zeros_like(b)
+    plan.execute(b.data_ptr(), q.data_ptr())
+    torch.cuda.synchronize()
+    plan.status()
+    return plan.diagnostics()
+
+
 def test_c3_patch_shapes(so):
-    """BASELINE config C3 geometry (n_sub=16, oversampling 3: up to 111 dofs per grid line, 49
-    coarse dofs, 448 boundary rows) on an 8x8 coarse grid: one patch of EVERY shape, the full
-    7x7-cell patch included, through the default kernel against the oracle."""
+    """C3's n_sub / oversampling (n_sub=16, l=3: up to 111 dofs per grid line, 49 coarse dofs) on
+    an 8x8 coarse grid: one patch of EVERY shape of that grid.  No patch of an 8x8 grid is interior
+    with l=3 -- its 7x7-cell patches touch two domain sides (225 id-99 boundary rows); C3's own
+    classes (448 and 337 rows) are covered by tests/test_gpu_c3.py on a 16x16 grid.  Decisions
+    (n_cut, n_dropped) must equal the oracle's wherever the oracle's are stable."""
     cfg, g = _mk(so, nref=3, n_sub=16, oversampling=3, stabilize=1)
     fields = make_fields(so, cfg, "D100")
     _upload(g, fields)
@@ -307,16 +323,22 @@ def test_c3_patch_shapes(so):
     ids = np.array(sorted(v[0] for v in shapes.values()), dtype=np.uint32)
     assert any(g.patch_layout(int(p)).mx == 7 and g.patch_layout(int(p)).my == 7 for p in ids)
     basis, premult, offs = g.compute_basis(ids)
-    worst = 0.0
+    dg = _decisions(g, ids, offs)
+    worst, widened = 0.0, 0
     for k, pid in enumerate(ids):
         p = so.patch_info(cfg, int(pid))
         spread, stable = so.selection_conditioning(cfg, fields, int(pid))
-        phi0, _, _ = so.patch_basis(cfg, fields, int(pid))
+        phi0, _, diag = so.patch_basis(cfg, fields, int(pid))
         err = np.abs(basis[int(offs[k]):int(offs[k]) + p.n_f] - phi0.ravel()).max()
+        if stable:
+            assert (dg[k].n_cut, dg[k].n_dropped) == (diag.n_cut[0], diag.n_dropped[0]), "patch %d" % pid
         tol = TOL_PHI if (stable and spread <= TOL_PHI) else max(TOL_PHI, 10.0 * spread)
+        widened += tol > TOL_PHI
         assert err <= tol, "C3 shape patch %d (%dx%d): %.3e (tol %.1e)" % (pid, p.mx, p.my, err, tol)
         worst = max(worst, err)
-    print("C3 shapes: %d patches, worst |dphi| %.3e" % (len(ids), worst))
+    # builder log gpurun_out/r2_l3b.log: the widened class is a minority of rim patches
+    assert widened <= len(ids) // 2, "%d of %d patches needed the widened tolerance" % (widened, len(ids))
+    print("C3 shapes: %d patches, worst |dphi| %.3e, %d with widened tolerance" % (len(ids), worst, widened))
 
 
 @pytest.mark.parametrize("n_sub", [8, 10, 12])
@@ -328,11 +350,14 @@ def test_large_line_blocks(so, n_sub):
     _upload(g, fields)
     ids = np.array([0, 3, 9, 27, 36], dtype=np.uint32)
     basis, premult, offs = g.compute_basis(ids)
+    dg = _decisions(g, ids, offs)
     for k, pid in enumerate(ids):
         p = so.patch_info(cfg, int(pid))
         spread, stable = so.selection_conditioning(cfg, fields, int(pid))
-        phi0, _, _ = so.patch_basis(cfg, fields, int(pid))
+        phi0, _, diag = so.patch_basis(cfg, fields, int(pid))
         err = np.abs(basis[int(offs[k]):int(offs[k]) + p.n_f] - phi0.ravel()).max()
+        if stable:
+            assert (dg[k].n_cut, dg[k].n_dropped) == (diag.n_cut[0], diag.n_dropped[0]), "patch %d" % pid
         tol = TOL_PHI if (stable and spread <= TOL_PHI) else max(TOL_PHI, 10.0 * spread)
         assert err <= tol, "n_sub %d patch %d: %.3e (tol %.1e)" % (n_sub, pid, err, tol)
 
