@@ -241,6 +241,7 @@ namespace
     a.vinv      = p->ws_v;
     a.v_stride  = p->v_stride;
     a.m_max     = p->m_max;
+    a.L_max     = p->L_max;
     a.xs        = p->ws_x;
     a.zs        = p->ws_z ? p->ws_z : p->ws_x;
     a.x_stride  = p->x_stride;
@@ -550,14 +551,14 @@ int slod_plan_create(slod_handle *h, const uint32_t *gids, size_t n, const uint6
   p->nb_buf = std::min(p->nb_max, std::max(s == 1 ? 96 : 80, p->nc_max + 16));
   // the kernel family, its LDS size and the fused stages are fixed here, once (the same function
   // the launch uses): a plan that no kernel can run is rejected now, not at execute
-  if (!slod_choose_solver(s, p->m_max, p->nc_max, p->nb_buf, p->nf_max, n, slod_read_tuning(), &p->choice))
+  if (!slod_choose_solver(s, n_sub, p->m_max, p->L_max, p->nc_max, p->nb_buf, p->nf_max, n, slod_read_tuning(), &p->choice))
     {
       delete p;
       return fail(h, SLOD_ERR_UNSUPPORTED, "slod_plan_create: patch does not fit the 160 KB LDS of any solver kernel");
     }
   p->nn_max    = (p->nn_max + 31) & ~31; // 256-byte aligned stencil planes
   p->st_stride = (size_t)9 * s * s * p->nn_max;
-  p->v_stride  = (size_t)p->L_max * p->choice.v_line_elems;
+  p->v_stride  = p->choice.v_patch_elems ? p->choice.v_patch_elems : (size_t)p->L_max * p->choice.v_line_elems;
   p->x_stride  = (size_t)p->L_max * p->m_max * p->nc_max;
   const bool   own_z = p->choice.kind == SLOD_K_TW;
   const size_t per_patch = (p->st_stride + p->v_stride + (own_z ? 2 : 1) * p->x_stride) * sizeof(double);

@@ -70,6 +70,8 @@ struct SlodKernelArgs
   double *vinv;
   size_t  v_stride;
   int32_t m_max;
+  int32_t L_max;    // most interior lines of a patch of the plan
+  int32_t nv;       // k_solve_nd: cell size of the dissection (fine elements per side)
   double *xs;
   double *zs;       // k_solve_tw: Z of the forward sweep (same strides as xs); other kernels keep Z in xs
   size_t  x_stride;
@@ -92,7 +94,8 @@ enum SlodSolverKind : int32_t
   SLOD_K_MF   = 1, // slod_solve_mf.hip
   SLOD_K_TW   = 2, // slod_solve_tw.hip
   SLOD_K_WS   = 3, // slod_solve_ws.hip
-  SLOD_K_COOP = 4  // slod_solve_coop.hip
+  SLOD_K_COOP = 4, // slod_solve_coop.hip
+  SLOD_K_ND   = 5  // slod_solve_nd.hip
 };
 
 // tuning knobs (environment, read once per plan) and the resulting kernel choice: slod_dispatch.cpp
@@ -111,9 +114,11 @@ struct SlodSolveChoice
   int    fuse_select = 0, fuse_assemble = 0, m_fused = 0, twisted = 0, debug = 0;
   int    v_line_pad = 0; // rows = columns of a V line as the kernel sees it
   size_t v_line_elems = 0; // doubles per stored V line (k_solve_tw: the 36 upper lane tiles only)
+  int    nv = 0;            // k_solve_nd: cell size
+  size_t v_patch_elems = 0; // k_solve_nd: doubles of scratch per patch (replaces L_max * v_line_elems)
 };
 SlodTuning slod_read_tuning();
-bool       slod_choose_solver(int S, int m_max, int nc_max, int nb_buf, int nf_max, size_t n_patches,
+bool       slod_choose_solver(int S, int n_sub, int m_max, int L_max, int nc_max, int nb_buf, int nf_max, size_t n_patches,
                               const SlodTuning &t, SlodSolveChoice *out);
 
 // launchers (slod_assemble.hip, slod_solve_{mf,tw,ws,coop}.hip, slod_select.hip)
@@ -123,6 +128,10 @@ hipError_t slod_launch_solve_mf(int S, const SlodKernelArgs &a, int n_patches, s
 hipError_t slod_launch_solve_tw(int S, const SlodKernelArgs &a, int n_patches, size_t lds, hipStream_t st);
 hipError_t slod_launch_solve_ws(int S, const SlodKernelArgs &a, int n_patches, size_t lds, hipStream_t st);
 hipError_t slod_launch_solve_coop(int S, int twisted, const SlodKernelArgs &a, int n_patches, hipStream_t st);
+hipError_t slod_launch_solve_nd(const SlodKernelArgs &a, int n_patches, size_t lds, hipStream_t st);
+int        slod_solve_nd_cell(int S, int n_sub, int m_max, int L_max); // cell size, 0 = not applicable
+size_t     slod_solve_nd_scratch(int nv, int m_max, int L_max, int nc_max);
+size_t     slod_solve_nd_lds_bytes(int nv, int m_max, int nc_max);
 hipError_t slod_launch_select(int S, const SlodKernelArgs &a, int n_patches, int nb_max,
                               int nf_max, hipStream_t st);
 size_t     slod_solve_lds_bytes(int S, int m_max, int nc_max, int twisted);

@@ -17,7 +17,7 @@ SlodTuning slod_read_tuning()
   SlodTuning t;
   if (const char *sel = getenv("SLOD_SOLVE"))
     t.solver = !strcmp(sel, "mf") ? SLOD_K_MF : !strcmp(sel, "tw") ? SLOD_K_TW : !strcmp(sel, "ws") ? SLOD_K_WS :
-               !strcmp(sel, "coop") ? SLOD_K_COOP : 0;
+               !strcmp(sel, "coop") ? SLOD_K_COOP : !strcmp(sel, "nd") ? SLOD_K_ND : 0;
   if (const char *e = getenv("SLOD_FUSE_SELECT"))
     t.fuse_select = atoi(e) ? 1 : 0;
   if (const char *e = getenv("SLOD_FUSE_ASSEMBLE"))
@@ -33,11 +33,15 @@ SlodTuning slod_read_tuning()
   return t;
 }
 
-bool slod_choose_solver(int S, int m_max, int nc_max, int nb_buf, int nf_max, size_t n_patches, const SlodTuning &t,
-                        SlodSolveChoice *out)
+bool slod_choose_solver(int S, int n_sub, int m_max, int L_max, int nc_max, int nb_buf, int nf_max, size_t n_patches,
+                        const SlodTuning &t_in, SlodSolveChoice *out)
 {
   const size_t    lds_max = 160 * 1024;
   SlodSolveChoice c;
+  const int       nd_nv = slod_solve_nd_cell(S, n_sub, m_max, L_max);
+  SlodTuning      t     = t_in;
+  if (t.solver == SLOD_K_ND && nd_nv == 0)
+    t.solver = 0; // nested dissection does not take this plan (vector problem, cell size): automatic choice
   c.debug = t.debug;
   // Kernel families:
   //   tw   twisted + wave-specialised VALU Gauss-Jordan (default: fastest on every BASELINE size,
@@ -52,7 +56,19 @@ bool slod_choose_solver(int S, int m_max, int nc_max, int nb_buf, int nf_max, si
   const size_t lds_sel = slod_select_lds_bytes(S, nb_buf, nc_max, nf_max);
   const bool   mf_fits = slod_solve_mf_tiles(S, m_max) > 0 && slod_solve_mf_lds_bytes(S, m_max, nc_max) <= lds_max;
   const bool   tw_fits = ws_fits && slod_solve_tw_lds_bytes(S, m_max, nc_max) <= lds_max;
-  if (mf_fits && (t.solver == SLOD_K_MF || (t.solver == 0 && !tw_fits && !ws_fits)))
+  if (nd_nv > 0 && t.solver == SLOD_K_ND)
+    {
+      //   nd   nested dissection: static condensation per cell, edge sets, skeleton lines
+      c.kind          = SLOD_K_ND;
+      c.nv            = nd_nv;
+      c.lds           = slod_solve_nd_lds_bytes(nd_nv, m_max, nc_max);
+      c.v_patch_elems = slod_solve_nd_scratch(nd_nv, m_max, L_max, nc_max);
+      c.fuse_assemble = t.fuse_assemble ? 1 : 0;
+      c.fuse_select   = (t.fuse_select && lds_sel <= 64 * 1024) ? 1 : 0;
+      if (c.fuse_select && lds_sel > c.lds)
+        c.lds = lds_sel;
+    }
+  else if (mf_fits && (t.solver == SLOD_K_MF || (t.solver == 0 && !tw_fits && !ws_fits)))
     {
       c.kind          = SLOD_K_MF;
       c.lds           = slod_solve_mf_lds_bytes(S, m_max, nc_max);
@@ -126,6 +142,9 @@ hipError_t slod_launch_solve(int S, const SlodSolveChoice &c, SlodKernelArgs &a,
         return slod_launch_solve_ws(S, a, n_patches, c.lds, st);
       case SLOD_K_COOP:
         return slod_launch_solve_coop(S, c.twisted, a, n_patches, st);
+      case SLOD_K_ND:
+        a.nv = c.nv;
+        return slod_launch_solve_nd(a, n_patches, c.lds, st);
       default:
         return hipErrorInvalidValue;
     }

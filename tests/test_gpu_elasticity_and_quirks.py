@@ -163,11 +163,12 @@ def test_size_independent_properties_at_full_size(so):
         assert distinct.size <= (2 * info.mx - 1) * (2 * info.my - 1) + 1
 
 
-@pytest.mark.parametrize("mode", ["mf", "tw", "ws", "coop"])
+@pytest.mark.parametrize("mode", ["mf", "tw", "ws", "coop", "nd"])
 @pytest.mark.parametrize("spacedim", [1, 2])
 def test_all_solver_kernels(so, mode, spacedim, monkeypatch):
-    """The four patch-solve kernel families (MFMA-factorised = default, twisted wave-specialised,
-    wave-specialised, cooperative) must all meet the parity bar; SLOD_SOLVE selects one per plan."""
+    """The patch-solve kernel families (twisted wave-specialised = default, MFMA-factorised,
+    wave-specialised, cooperative, nested dissection -- scalar problems only, vector plans fall back
+    to the default) must all meet the parity bar; SLOD_SOLVE selects one per plan."""
     monkeypatch.setenv("SLOD_SOLVE", mode)
     kw = dict(nref=3, n_sub=4, oversampling=1, stabilize=1) if spacedim == 1 else \
         dict(nref=2, n_sub=4, oversampling=1, spacedim=2, stabilize=1)
@@ -405,3 +406,42 @@ def test_balanced_launch_order_is_transparent(so, monkeypatch):
     d0 = [(d.path, d.n_cut, d.n_dropped) for d in plan0.diagnostics()]
     assert np.array_equal(b0, b1) and np.array_equal(p0, p1)
     assert d0 == d1 and len(set(d1)) > 1          # rim and full patches decide differently
+
+
+@pytest.mark.parametrize("kw,ids", [
+    (dict(nref=3, n_sub=4, oversampling=1), None),
+    (dict(nref=4, n_sub=4, oversampling=2), None),
+    (dict(nref=4, n_sub=4, oversampling=3, dist="D100"), range(0, 256, 5)),
+    (dict(nref=5, n_sub=8, oversampling=2), range(0, 1024, 13)),
+])
+def test_nested_dissection_solver(so, kw, ids, monkeypatch, capfd):
+    """SLOD_SOLVE=nd: static condensation per cell + edge sets + skeleton lines (k_solve_nd) instead
+    of the line-by-line elimination.  X = A_II^-1 P^T_I itself (slod_patch_solution) and the basis
+    against the oracle, on every patch shape of the plan; the launch log proves the kernel ran."""
+    monkeypatch.setenv("SLOD_SOLVE", "nd")
+    monkeypatch.setenv("SLOD_DEBUG", "1")
+    kw = dict(kw)
+    dist = kw.pop("dist", "D1e4")
+    cfg, g = _mk(so, stabilize=1, **kw)
+    fields = make_fields(so, cfg, dist)
+    _upload(g, fields)
+    shapes = {}
+    for pid in range(g.num_patches):
+        i = g.patch_layout(pid)
+        shapes.setdefault((i.mx, i.my, tuple(i.side_domain)), pid)
+    for pid in sorted(shapes.values()):
+        X = g.patch_solution(pid)
+        ref = so.patch_debug(cfg, fields, pid)["X"]
+        assert np.abs(X - ref).max() <= 1e-11 * np.abs(ref).max(), "patch %d" % pid
+    pids = np.array(sorted(set(shapes.values()) | set(ids if ids is not None else range(g.num_patches))), dtype=np.uint32)
+    basis, premult, offs = g.compute_basis(pids)
+    assert "k_solve_nd<" in capfd.readouterr().err
+    for k, pid in enumerate(pids):
+        if kw["oversampling"] >= 3:   # ill-conditioned rim patches: the rule of test_selection_stage_paths
+            p = so.patch_info(cfg, int(pid))
+            spread, stable = so.selection_conditioning(cfg, fields, int(pid))
+            phi0, _, _ = so.patch_basis(cfg, fields, int(pid))
+            err = np.abs(basis[int(offs[k]):int(offs[k]) + p.n_f] - phi0.ravel()).max()
+            assert err <= (TOL_PHI if (stable and spread <= TOL_PHI) else max(TOL_PHI, 10.0 * spread)), "patch %d" % pid
+        else:
+            _check_patch(so, cfg, fields, int(pid), basis, premult, int(offs[k]), "nd")
