@@ -230,6 +230,51 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed, allgather_ms = float(tmax[0]), float(tmax[1])
 
+    # The same exchange through the C-ABI (what a C++ host calls: slod_comm_* over RCCL,
+    # slod_plan_execute_allgather computes the rank's block in pieces and broadcasts every finished
+    # piece on a second stream while the next one computes).  Outside the metric.  The gathered slabs
+    # must equal the torch.distributed result bit for bit.  A watchdog prints the headline line and
+    # leaves if this leg does not come back (it has never run on more than one GPU before the
+    # driver's scaling run).
+    abi_exchange = None
+    headline = {}
+    if world > 1:
+        import threading
+
+        def bail():
+            if rank == 0 and headline:
+                headline["abi_exchange"] = {"error": "slod_plan_execute_allgather did not return within 60 s"}
+                print(json.dumps(headline), flush=True)
+            os._exit(0 if headline or rank != 0 else 1)
+        watchdog = threading.Timer(60.0, bail)
+        watchdog.daemon = True
+    else:
+        watchdog = None
+
+    def run_abi_exchange():
+        ident = [slod_amd.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ident, src=0)
+        comm = slod_amd.Comm(ident[0], world, rank, local_rank)
+        ppr = sd.slab_patches(total, world)
+        gb2 = torch.zeros(world * basis.numel(), dtype=torch.float64, device=dev)
+        gp2 = torch.zeros_like(gb2)
+        cs, xs = torch.cuda.Stream(), torch.cuda.Stream()
+        res = {}
+        for n_pieces in (1, 4):
+            for rep in range(2):
+                barrier()
+                ta = time.perf_counter()
+                plan.execute_allgather(comm, gb2.data_ptr(), gp2.data_ptr(), ppr, n_pieces, cs.cuda_stream, xs.cuda_stream)
+                barrier()
+                te = (time.perf_counter() - ta) * 1e3
+            plan.status()
+            ok = bool(torch.equal(gb2, gb)) and bool(torch.equal(gp2, gp))
+            tt = torch.tensor([te, 0.0 if ok else 1.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            res["pieces_%d" % n_pieces] = {"step_plus_exchange_ms": float(tt[0]), "equals_torch_allgather": float(tt[1]) == 0.0}
+        comm.close()
+        return res
+
     if rank == 0:
         flops, nbytes = canonical_counts(slod, gids)
         ms_step = elapsed / args.steps * 1e3
@@ -274,7 +319,18 @@ def main():
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(CFG, fields[probs[0]], NP, every={"C2": 1, "C3": 256, "C4": 8}[args.config])
-        print(json.dumps(out))
+        headline.update(out)
+    if world > 1:
+        dist.barrier()            # rank 0 comes out of its CPU-baseline leg here
+        watchdog.start()
+        try:
+            abi_exchange = run_abi_exchange()
+        except Exception as e:    # noqa: BLE001 -- reported in the line, never fatal for the metric
+            abi_exchange = {"error": "%s: %s" % (type(e).__name__, e)}
+        watchdog.cancel()
+    if rank == 0:
+        out["abi_exchange"] = abi_exchange
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -564,15 +564,21 @@ int slod_plan_create(slod_handle *h, const uint32_t *gids, size_t n, const uint6
   const size_t per_patch = (p->st_stride + p->v_stride + (own_z ? 2 : 1) * p->x_stride) * sizeof(double);
   // Workspace budget: 24 GB, or 60 % of what is free on the device if that is more (an MI355X has
   // 288 GB: big plans then run in few, long launches -- C3 in 3 chunks instead of 14, less idle
-  // tail per chunk); SLOD_WORKSPACE_MB overrides
+  // tail per chunk), never more than 80 % of what is free right now (the caller's outputs and
+  // further plans of the handle need room too: allocate outputs BEFORE the plan, or they compete
+  // with it); SLOD_WORKSPACE_MB overrides.  If an allocation still fails the chunk is halved and
+  // tried again: the plan degrades to more, shorter launches instead of failing.
   size_t budget_mb = 24 * 1024;
   {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-      budget_mb = std::max<size_t>(budget_mb, free_b / (1024 * 1024) * 6 / 10);
+      {
+        const size_t free_mb = free_b / (1024 * 1024);
+        budget_mb = std::min(std::max<size_t>(budget_mb, free_mb * 6 / 10), std::max<size_t>(64, free_mb * 8 / 10));
+      }
   }
   if (const char *env = std::getenv("SLOD_WORKSPACE_MB"))
-    budget_mb = (size_t)std::max(64L, std::atol(env));
+    budget_mb = (size_t)std::max(1L, std::atol(env));
   p->chunk = std::max<size_t>(1, std::min<size_t>(n, budget_mb * 1024 * 1024 / per_patch));
   bool ok  = true;
   ok       = ok && hipMalloc((void **)&p->d_desc, n * sizeof(SlodPatchDesc)) == hipSuccess;
@@ -582,18 +588,38 @@ int slod_plan_create(slod_handle *h, const uint32_t *gids, size_t n, const uint6
   // a finite number.
   p->guard = (size_t)24 * p->nc_max + 64;
   const size_t st_slack = (size_t)4 * p->nn_max;
-  ok       = ok && hipMalloc((void **)&p->ws_st, (p->chunk * p->st_stride + st_slack) * sizeof(double)) == hipSuccess;
-  ok       = ok && hipMemset(p->ws_st, 0, (p->chunk * p->st_stride + st_slack) * sizeof(double)) == hipSuccess;
-  ok       = ok && hipMalloc((void **)&p->ws_v, p->chunk * p->v_stride * sizeof(double)) == hipSuccess;
-  ok       = ok && hipMalloc((void **)&p->ws_x_alloc, (p->chunk * p->x_stride + 2 * p->guard) * sizeof(double)) == hipSuccess;
-  ok       = ok && hipMemset(p->ws_x_alloc, 0, (p->chunk * p->x_stride + 2 * p->guard) * sizeof(double)) == hipSuccess;
-  p->ws_x  = p->ws_x_alloc ? p->ws_x_alloc + p->guard : nullptr;
-  if (own_z)
+  auto free_ws = [&]() {
+    for (double **q : {&p->ws_st, &p->ws_v, &p->ws_x_alloc, &p->ws_z, &p->ws_m})
+      if (*q)
+        {
+          (void)hipFree(*q);
+          *q = nullptr;
+        }
+    p->ws_x = nullptr;
+  };
+  for (;;)
     {
-      ok = ok && hipMalloc((void **)&p->ws_z, (p->chunk * p->x_stride + p->guard) * sizeof(double)) == hipSuccess;
-      ok = ok && hipMemset(p->ws_z, 0, (p->chunk * p->x_stride + p->guard) * sizeof(double)) == hipSuccess;
+      bool w = ok;
+      w      = w && hipMalloc((void **)&p->ws_st, (p->chunk * p->st_stride + st_slack) * sizeof(double)) == hipSuccess;
+      w      = w && hipMalloc((void **)&p->ws_v, std::max<size_t>(1, p->chunk * p->v_stride) * sizeof(double)) == hipSuccess;
+      w      = w && hipMalloc((void **)&p->ws_x_alloc, (p->chunk * p->x_stride + 2 * p->guard) * sizeof(double)) == hipSuccess;
+      if (own_z)
+        w = w && hipMalloc((void **)&p->ws_z, (p->chunk * p->x_stride + p->guard) * sizeof(double)) == hipSuccess;
+      w = w && hipMalloc((void **)&p->ws_m, p->chunk * (size_t)p->nc_max * p->nc_max * sizeof(double)) == hipSuccess;
+      if (w || !ok || p->chunk == 1)
+        {
+          ok = w;
+          break;
+        }
+      (void)hipGetLastError(); // out of memory: clear it, halve the chunk, try again
+      free_ws();
+      p->chunk = (p->chunk + 1) / 2;
     }
-  ok       = ok && hipMalloc((void **)&p->ws_m, p->chunk * (size_t)p->nc_max * p->nc_max * sizeof(double)) == hipSuccess;
+  ok      = ok && hipMemset(p->ws_st, 0, (p->chunk * p->st_stride + st_slack) * sizeof(double)) == hipSuccess;
+  ok      = ok && hipMemset(p->ws_x_alloc, 0, (p->chunk * p->x_stride + 2 * p->guard) * sizeof(double)) == hipSuccess;
+  p->ws_x = p->ws_x_alloc ? p->ws_x_alloc + p->guard : nullptr;
+  if (own_z)
+    ok = ok && hipMemset(p->ws_z, 0, (p->chunk * p->x_stride + p->guard) * sizeof(double)) == hipSuccess;
   ok       = ok && hipMalloc((void **)&p->d_status, sizeof(int32_t)) == hipSuccess;
   ok       = ok && hipMalloc((void **)&p->d_pdiag, n * (size_t)s * sizeof(SlodPatchDiag)) == hipSuccess;
   ok       = ok && hipMemset(p->d_pdiag, 0, n * (size_t)s * sizeof(SlodPatchDiag)) == hipSuccess;
@@ -767,6 +793,8 @@ int slod_plan_kernel_ms(slod_plan *p, float ms[3])
   if (!p->ran)
     return fail(p->h, SLOD_ERR_STATE, "slod_plan_kernel_ms: plan has not been executed");
   const size_t slots = std::min<size_t>(p->n_exec, (size_t)p->depth);
+  if (slots == 0)
+    return fail(p->h, SLOD_ERR_STATE, "slod_plan_kernel_ms: the last execute recorded no events (slod_plan_execute_allgather)");
   double       acc[3] = {0, 0, 0};
   for (size_t sl = 0; sl < slots; ++sl)
     for (size_t c = 0; c < p->n_chunks; ++c)
@@ -1178,8 +1206,8 @@ int slod_plan_execute_allgather(slod_plan *p, slod_comm *c, double *d_basis_all,
     return hip_fail(h, e, "slod_plan_execute_allgather");
   if (p->n)
     {
-      p->ran = true;
-      ++p->n_exec;
+      p->ran    = true;
+      p->n_exec = 0; // no events were recorded for this execute: slod_plan_kernel_ms has nothing to report
     }
   return SLOD_OK;
 }

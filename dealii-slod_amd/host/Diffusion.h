@@ -10,42 +10,46 @@
 
 namespace slod
 {
+  // Piecewise-constant field on a uniform 2^r x 2^r grid of the unit square, one draw of the C library
+  // generator per grid cell in row order (x fastest).  What must agree with the reference bit for
+  // bit is the draw itself (Diffusion.h:30-36): lo + float(rand()) / float(RAND_MAX / (hi - lo));
+  // slod_sample_coefficient evaluates the same table on the device.
   template <int dim>
   class problem_parameter : public Function<dim>
   {
-  private:
-    const double        min_val;
-    const double        max_val;
-    const unsigned int  refinement;
-    std::vector<double> random_values;
-    unsigned int        N_cells_per_line;
-    double              eta;
+    static_assert(dim == 2, "the reference samples x and y only (Diffusion.h:47-51)");
 
   public:
-    problem_parameter(double min, double max, unsigned int r)
-      : min_val(min)
-      , max_val(max)
-      , refinement(r)
+    problem_parameter(double lo, double hi, unsigned int r)
+      : cells_per_side(1u << r)
+      , constant(lo == hi)
+      , constant_value(lo)
     {
-      N_cells_per_line     = 1u << refinement;
-      eta                  = (double)1 / N_cells_per_line;
-      unsigned int N_cells = 1;
-      for (int d = 0; d < dim; ++d)
-        N_cells *= N_cells_per_line;
-      if (max_val != min_val)
-        for (unsigned int i = 0; i < N_cells; ++i)
-          random_values.push_back(min_val + static_cast<float>(rand()) /
-                                              (static_cast<float>(RAND_MAX / (max_val - min_val))));
+      if (constant)
+        return;
+      table.resize((size_t)cells_per_side * cells_per_side);
+      const float inv_range = static_cast<float>(RAND_MAX / (hi - lo));
+      for (double &t : table)
+        t = lo + static_cast<float>(rand()) / inv_range;
     }
 
     double value(const Point<dim> &p, const unsigned int = 0) const override
     {
-      if (max_val == min_val) // constant coefficients
-        return min_val;
-      const unsigned int vector_cell_index =
-        (int)std::floor(p(0) / eta) + N_cells_per_line * (int)std::floor(p(1) / eta);
-      return random_values[vector_cell_index];
+      if (constant)
+        return constant_value;
+      const double   cells = (double)cells_per_side; // eta = 1 / cells; the reference divides by eta
+      const double   eta = 1.0 / cells;
+      const unsigned cx = (unsigned)(int)std::floor(p(0) / eta), cy = (unsigned)(int)std::floor(p(1) / eta);
+      return table[cx + (size_t)cells_per_side * cy];
     }
+
+    unsigned int grid_cells_per_side() const { return cells_per_side; }
+
+  private:
+    unsigned int        cells_per_side;
+    bool                constant;
+    double              constant_value;
+    std::vector<double> table;
   };
 
   template <int dim, int spacedim>

@@ -131,7 +131,8 @@ int slod_plan_execute(slod_plan *p, double *d_basis, double *d_premult, void *hi
 /* Keep HIP-event records of the next `depth` executes (default 1 = the last one only);
  * resets the record.  The events sit on the stream the kernels are launched on. */
 int slod_plan_profile(slod_plan *p, int depth);
-/* mean per-kernel device time over the recorded executes (HIP events around every launch);
+/* mean per-kernel device time over the recorded executes (HIP events around every launch of
+ * slod_plan_execute; slod_plan_execute_allgather records none: SLOD_ERR_STATE after it);
  * synchronises.  ms[0] assemble, ms[1] patch solve, ms[2] selection */
 int slod_plan_kernel_ms(slod_plan *p, float ms[3]);
 /* numerical status of the last execute (0 or SLOD_ERR_NUMERIC); synchronises. */
@@ -168,7 +169,8 @@ int slod_compute_basis(slod_handle *h, const uint32_t *gids, size_t n, double *b
  * writes and what the all-gather of the multi-GPU path produces): patch p at
  * d_basis[p * stride + d * n_fine(p) + dof].  Overlaps of patches are index arithmetic on
  * the patch-lexicographic layout; no deal.II numbering is involved. */
-/* Upper bound of patches q whose node set meets that of one patch: (4 l + 1)^2. */
+/* Upper bound of patches q whose node set meets that of one patch: (4 l + 3)^2 (the closed patches
+ * of two cells share a node as soon as their centres are at most 2 l + 1 cells apart per axis). */
 int slod_lod_row_capacity(const slod_handle *h);
 /* Patches coupled with `patch_id` in A_LOD (LOD.cc:970-971 pattern of Tmmult), ascending ids;
  * returns their count.  HOST buffer. */
@@ -178,7 +180,8 @@ int slod_lod_pattern(const slod_handle *h, uint32_t patch_id, uint32_t *neighbou
  *   d_values[(k * cap + j) * s * s + d * s + e] = sum_i phi_{rows[k],d}(i) psi_{q,e}(i),
  *   q = d_cols[k * cap + j]  (0xffffffff = unused slot), cap = slod_lod_row_capacity().
  * Column (q,e) of the reference matrix is spacedim * q + e (LOD.cc:942-944).  rows is a HOST
- * array; d_* are DEVICE pointers; asynchronous on hip_stream. */
+ * array; d_* are DEVICE pointers.  The call uploads the row list (a device allocation of its own) and
+ * returns after hip_stream has finished the kernel: it SYNCHRONISES hip_stream. */
 int slod_lod_matrix(slod_handle *h, const uint32_t *rows, size_t n_rows, const double *d_basis,
                     const double *d_premult, size_t stride, double *d_values, uint32_t *d_cols,
                     void *hip_stream);

@@ -445,3 +445,54 @@ def test_nested_dissection_solver(so, kw, ids, monkeypatch, capfd):
             assert err <= (TOL_PHI if (stable and spread <= TOL_PHI) else max(TOL_PHI, 10.0 * spread)), "patch %d" % pid
         else:
             _check_patch(so, cfg, fields, int(pid), basis, premult, int(offs[k]), "nd")
+
+
+@pytest.mark.parametrize("balance", ["1", "0"])
+def test_chunked_plan_equals_single_launch(so, monkeypatch, balance):
+    """SLOD_WORKSPACE_MB small enough that the plan runs in many workspace chunks (several launches,
+    slots re-used, balanced launch order per plan): bit-identical to the one-launch plan, decisions
+    and status included."""
+    import torch
+    monkeypatch.setenv("SLOD_BALANCE", balance)
+    cfg, g = _mk(so, nref=4, n_sub=4, oversampling=2, stabilize=1)
+    fields = make_fields(so, cfg, "D1e4")
+    _upload(g, fields)
+    ids = np.arange(g.num_patches, dtype=np.uint32)[::-1].copy()
+    b1, p1, offs = g.compute_basis(ids)
+    monkeypatch.setenv("SLOD_WORKSPACE_MB", "2")
+    b2, p2, _ = g.compute_basis(ids)
+    assert np.array_equal(b1, b2) and np.array_equal(p1, p2)
+    plan = g.plan(ids)
+    dev = torch.device("cuda", 0)
+    tb = torch.zeros(len(ids) * plan.stride, dtype=torch.float64, device=dev)
+    tq = torch.zeros_like(tb)
+    plan.execute(tb.data_ptr(), tq.data_ptr())
+    plan.status()
+    ms = plan.kernel_ms()
+    assert ms[1] > 0.0
+    dg = plan.diagnostics()
+    for k in range(0, len(ids), 17):
+        p = so.patch_info(cfg, int(ids[k]))
+        assert np.array_equal(tb[k * plan.stride:k * plan.stride + p.n_f].cpu().numpy(), b1[int(offs[k]):int(offs[k]) + p.n_f])
+        d0 = so.patch_basis(cfg, fields, int(ids[k]))[2]
+        assert (dg[k].n_cut, dg[k].n_dropped) == (d0.n_cut[0], d0.n_dropped[0])
+
+
+@pytest.mark.parametrize("dist", ["D100", "D1e4"])
+def test_elasticity_c4_sample_with_projection_quirk(so, dist):
+    """C4 as a dealii-slod elasticity run would configure it: adapter/LOD_hip.cc passes
+    projection_quirk = (spacedim == 2), i.e. the row-parity component assignment of
+    projection_P1_P0<2,2> (LODtools.h:43-67).  One patch of every shape plus every 16th patch."""
+    cfg, g = _mk(so, nref=5, n_sub=8, oversampling=2, spacedim=2, stabilize=1, proj_quirk=1)
+    fields = make_fields(so, cfg, dist)
+    _upload(g, fields)
+    shapes = {}
+    for pid in range(g.num_patches):
+        i = g.patch_layout(pid)
+        shapes.setdefault((i.mx, i.my, tuple(i.side_domain)), pid)
+    ids = np.array(sorted(set(shapes.values()) | set(range(0, g.num_patches, 16))), dtype=np.uint32)
+    basis, premult, offs = g.compute_basis(ids)
+    worst = 0.0
+    for k, pid in enumerate(ids):
+        worst = max(worst, _check_patch(so, cfg, fields, int(pid), basis, premult, int(offs[k]), "C4 quirk")[0])
+    print("C4 with projection quirk, %s: %d patches, worst |dphi| %.3e" % (dist, len(ids), worst))
