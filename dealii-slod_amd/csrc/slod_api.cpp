@@ -51,6 +51,8 @@ struct slod_plan
   int                        depth = 1; // event slots (slod_plan_profile)
   size_t                     n_exec = 0;
   bool                       ran = false;
+  bool                       uniform_stride = true; // NULL offsets: patch k at k * stride
+  std::vector<char>          prob_used;             // [n_problems] coefficient realisations the plan reads
 };
 
 namespace
@@ -130,51 +132,6 @@ namespace
   {
     const int f = 2 * h->cfg.oversampling + 1;
     return g.mx == f && g.my == f;
-  }
-
-  SlodPatchDesc make_desc(const slod_handle *h, uint32_t gid)
-  {
-    const uint32_t  prob = gid / (uint32_t)h->NP, pid = gid % (uint32_t)h->NP;
-    const PatchGeom g = patch_geom(h, pid);
-    slod_patch_info info;
-    fill_info(h, g, &info);
-    const int     n = h->cfg.n_subdivisions, s = h->cfg.spacedim;
-    SlodPatchDesc d;
-    std::memset(&d, 0, sizeof(d));
-    d.ox = g.x0 * n;
-    d.oy = g.y0 * n;
-    if (h->cfg.constant_coefficients && is_full(h, g) && h->first_full >= 0)
-      {
-        // quirk Q1 (LOD.cc:354-362,446-450): later full patches copy the first one's matrix
-        const PatchGeom f = patch_geom(h, (uint32_t)h->first_full);
-        d.ox              = f.x0 * n;
-        d.oy              = f.y0 * n;
-      }
-    d.nx    = info.nx;
-    d.ny    = info.ny;
-    d.mx    = g.mx;
-    d.my    = g.my;
-    d.ccx   = g.cx - g.x0;
-    d.ccy   = g.cy - g.y0;
-    d.flags = (g.side_domain[0] ? 1 : 0) | (g.side_domain[1] ? 2 : 0) | (g.side_domain[2] ? 4 : 0) |
-              (g.side_domain[3] ? 8 : 0);
-    if (info.is_lod)
-      d.flags |= SLOD_F_LOD;
-    if (info.nx > info.ny)
-      {
-        d.flags |= SLOD_F_TRANSPOSED;
-        d.m = s * (info.ny - 1);
-        d.L = info.nx - 1;
-      }
-    else
-      {
-        d.m = s * (info.nx - 1);
-        d.L = info.ny - 1;
-      }
-    d.n_c  = info.n_coarse;
-    d.n_b  = info.n_boundary;
-    d.prob = (int32_t)prob;
-    return d;
   }
 
   // stream + coefficient storage; called by every entry point that touches the device
@@ -503,57 +460,89 @@ int slod_plan_create(slod_handle *h, const uint32_t *gids, size_t n, const uint6
   slod_plan     *p     = new slod_plan;
   p->h                 = h;
   p->n                 = n;
-  p->desc.resize(n);
   const int s = h->cfg.spacedim, n_sub = h->cfg.n_subdivisions, full = 2 * h->cfg.oversampling + 1;
   // uniform stride = the full patch's s vectors of n_fine (what an all-gather slab uses)
-  p->stride = (size_t)s * s * (size_t)(n_sub * full + 1) * (size_t)(n_sub * full + 1);
-  int nb_min_slod = 1 << 30;
-  for (size_t k = 0; k < n; ++k)
-    {
-      if (gids[k] >= total)
-        {
-          delete p;
-          return fail(h, SLOD_ERR_ARGUMENT, "slod_plan_create: patch id out of range");
-        }
-      SlodPatchDesc d = make_desc(h, gids[k]);
-      d.out_off       = offsets ? offsets[k] : (uint64_t)k * p->stride;
-      d.plan_index    = (uint32_t)k;
-      const int nn    = (d.nx + 1) * (d.ny + 1);
-      p->m_max        = std::max(p->m_max, (int)d.m);
-      p->L_max        = std::max(p->L_max, (int)d.L);
-      p->nc_max       = std::max(p->nc_max, (int)d.n_c);
-      p->nb_max       = std::max(p->nb_max, (d.flags & SLOD_F_LOD) ? 0 : (int)d.n_b);
-      nb_min_slod     = (d.flags & SLOD_F_LOD) ? nb_min_slod : std::min(nb_min_slod, (int)d.n_b);
-      p->nn_max       = std::max(p->nn_max, nn);
-      p->nf_max       = std::max(p->nf_max, s * nn);
-      p->out_size     = std::max(p->out_size, (size_t)d.out_off + (size_t)s * s * nn);
-      p->desc[k]      = d;
-    }
+  p->stride         = (size_t)s * s * (size_t)(n_sub * full + 1) * (size_t)(n_sub * full + 1);
+  p->uniform_stride = offsets == nullptr;
   if (n == 0)
     {
       *out = p;
       return SLOD_OK;
     }
+  // The descriptors are built ON THE DEVICE (k_make_desc: create_patches + create_mesh_for_patch +
+  // index-set sizes per patch, LOD.cc:122-244,770-858), together with the plan's maxima, the id range
+  // check, the realisations in use and the balanced launch order (k_balance_order): no per-patch work
+  // on the host.  The host copy p->desc is one bulk read-back for the entry points that hand out
+  // per-patch data (slod_compute_basis, slod_plan_patch_layout).
+  (void)total;
+  int n_cu = 256;
+  (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->cfg.device);
+  n_cu               = std::max(n_cu, 1);
+  const bool balance = slod_read_tuning().balance && n > 1 && n <= 65536;
+  bool       ok      = hipMalloc((void **)&p->d_desc, n * sizeof(SlodPatchDesc)) == hipSuccess;
+  if (ok && balance)
+    ok = hipMalloc((void **)&p->d_desc_bal, n * sizeof(SlodPatchDesc)) == hipSuccess;
+  SlodPlanSummary sum;
+  std::memset(&sum, 0, sizeof(sum));
+  if (ok)
+    {
+      const hipError_t be = slod_build_descriptors(h, gids, n, offsets, p->stride, n_cu, balance, p->d_desc, p->d_desc_bal, &sum,
+                                                   &p->prob_used);
+      if (be != hipSuccess)
+        {
+          slod_plan_destroy(p);
+          return hip_fail(h, be, "slod_plan_create: descriptor kernels");
+        }
+    }
+  else
+    {
+      const hipError_t le = hipGetLastError();
+      slod_plan_destroy(p);
+      return hip_fail(h, le, "slod_plan_create: device allocation");
+    }
+  if (sum.error)
+    {
+      slod_plan_destroy(p);
+      return fail(h, SLOD_ERR_ARGUMENT, "slod_plan_create: patch id out of range");
+    }
+  p->m_max    = sum.m_max;
+  p->L_max    = sum.L_max;
+  p->nc_max   = sum.nc_max;
+  p->nb_max   = sum.nb_max;
+  p->nn_max   = sum.nn_max;
+  p->nf_max   = s * sum.nn_max;
+  p->out_size = (size_t)sum.out_size;
+  p->desc.resize(n);
+  if (hipMemcpy(p->desc.data(), p->d_desc, n * sizeof(SlodPatchDesc), hipMemcpyDeviceToHost) != hipSuccess)
+    {
+      const hipError_t le = hipGetLastError();
+      slod_plan_destroy(p);
+      return hip_fail(h, le, "slod_plan_create: descriptor read-back");
+    }
   if (p->m_max > 16 * 7)
     {
-      delete p;
+      slod_plan_destroy(p);
       return fail(h, SLOD_ERR_UNSUPPORTED, "slod_plan_create: more than 112 dofs per grid line");
     }
   if (p->nc_max > 64)
     {
-      delete p;
+      slod_plan_destroy(p);
       return fail(h, SLOD_ERR_UNSUPPORTED, "slod_plan_create: more than 64 coarse dofs per patch");
     }
-  (void)nb_min_slod;
   // k_select reduces the boundary-trace matrix by QR in row chunks (TSQR): the LDS buffer
   // holds nb_buf rows, at least nc_max + 16 so every chunk brings new rows
   // (vector problems: 80 rows keep k_select<2> under 80 KB of LDS, i.e. two workgroups per CU)
   p->nb_buf = std::min(p->nb_max, std::max(s == 1 ? 96 : 80, p->nc_max + 16));
   // the kernel family, its LDS size and the fused stages are fixed here, once (the same function
   // the launch uses): a plan that no kernel can run is rejected now, not at execute
+  if (p->nb_buf > 160) // k_select's register-resident reflector holds 16 lanes x NRL = 160 rows (slod_select.hip.h)
+    {
+      slod_plan_destroy(p);
+      return fail(h, SLOD_ERR_UNSUPPORTED, "slod_plan_create: boundary-trace buffer beyond the selection kernel's 160 rows");
+    }
   if (!slod_choose_solver(s, n_sub, p->m_max, p->L_max, p->nc_max, p->nb_buf, p->nf_max, n, slod_read_tuning(), &p->choice))
     {
-      delete p;
+      slod_plan_destroy(p);
       return fail(h, SLOD_ERR_UNSUPPORTED, "slod_plan_create: patch does not fit the 160 KB LDS of any solver kernel");
     }
   p->nn_max    = (p->nn_max + 31) & ~31; // 256-byte aligned stencil planes
@@ -580,8 +569,7 @@ int slod_plan_create(slod_handle *h, const uint32_t *gids, size_t n, const uint6
   if (const char *env = std::getenv("SLOD_WORKSPACE_MB"))
     budget_mb = (size_t)std::max(1L, std::atol(env));
   p->chunk = std::max<size_t>(1, std::min<size_t>(n, budget_mb * 1024 * 1024 / per_patch));
-  bool ok  = true;
-  ok       = ok && hipMalloc((void **)&p->d_desc, n * sizeof(SlodPatchDesc)) == hipSuccess;
+  ok = true;
   // Guards: the kernels read the banded neighbours of a row / node without range tests (the
   // matching band coefficient is zero, or the result is dropped), so up to a few rows before the
   // first and after the last slot are touched.  X is zero-filled once: a skipped product must meet
@@ -623,36 +611,11 @@ int slod_plan_create(slod_handle *h, const uint32_t *gids, size_t n, const uint6
   ok       = ok && hipMalloc((void **)&p->d_status, sizeof(int32_t)) == hipSuccess;
   ok       = ok && hipMalloc((void **)&p->d_pdiag, n * (size_t)s * sizeof(SlodPatchDiag)) == hipSuccess;
   ok       = ok && hipMemset(p->d_pdiag, 0, n * (size_t)s * sizeof(SlodPatchDiag)) == hipSuccess;
-  ok = ok && hipMemcpy(p->d_desc, p->desc.data(), n * sizeof(SlodPatchDesc), hipMemcpyHostToDevice) ==
-               hipSuccess;
-  if (ok && slod_read_tuning().balance && n > 1)
-    {
-      // Launch order.  All workgroups of a launch are resident at once (a few per CU) and the step
-      // ends with the slowest CU; measured on MI355X (tools/patch_timeline.py) the blocks b, b + n_cu,
-      // b + 2 n_cu, ... share a CU.  Patches sorted by estimated cost (canonical solve flops, rim
-      // patches are cheaper) and dealt in a snake over rows of n_cu give every CU the same mix.
-      int n_cu = 256;
-      (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->cfg.device);
-      n_cu = std::max(n_cu, 1);
-      std::vector<std::pair<double, uint32_t>> cost(n);
-      for (size_t k = 0; k < n; ++k)
-        {
-          const SlodPatchDesc &d = p->desc[k];
-          const double ni = (double)d.m * d.L, b = (double)d.m + s - 1;
-          cost[k] = {-(ni * (b * b + 3 * b) + 4.0 * d.n_c * ni * b + 200.0 * d.n_b * d.n_c), (uint32_t)k};
-        }
-      std::stable_sort(cost.begin(), cost.end());
-      std::vector<SlodPatchDesc> bal(n);
-      for (size_t r = 0; r < n; ++r)
-        {
-          const size_t row = r / (size_t)n_cu, col = r % (size_t)n_cu;
-          const size_t len = std::min<size_t>((size_t)n_cu, n - row * (size_t)n_cu);
-          const size_t pos = row * (size_t)n_cu + ((row & 1) ? len - 1 - col : col);
-          bal[pos]         = p->desc[cost[r].second];
-        }
-      ok = ok && hipMalloc((void **)&p->d_desc_bal, n * sizeof(SlodPatchDesc)) == hipSuccess;
-      ok = ok && hipMemcpy(p->d_desc_bal, bal.data(), n * sizeof(SlodPatchDesc), hipMemcpyHostToDevice) == hipSuccess;
-    }
+  // Launch order (d_desc_bal, built by k_balance_order above).  All workgroups of a launch are resident
+  // at once (a few per CU) and the step ends with the slowest CU; measured on MI355X
+  // (tools/patch_timeline.py) the blocks b, b + n_cu, b + 2 n_cu, ... share a CU.  Patches ranked by
+  // estimated cost (canonical solve flops, rim patches are cheaper) and dealt in a snake over rows of
+  // n_cu give every CU the same mix.
   ok = ok && hipMemset(p->d_status, 0, sizeof(int32_t)) == hipSuccess;
   p->n_chunks = (n + p->chunk - 1) / p->chunk;
   p->ev.assign(4 * p->n_chunks, nullptr);
@@ -708,9 +671,9 @@ int slod_plan_execute(slod_plan *p, double *d_basis, double *d_premult, void *hi
     return SLOD_OK;
   if (!d_basis || !d_premult)
     return fail(h, SLOD_ERR_ARGUMENT, "slod_plan_execute: null output pointer");
-  for (size_t k = 0; k < p->n; ++k)
-    for (int f = 0; f < h->cfg.spacedim; ++f)
-      if (!h->coef_set[(size_t)p->desc[k].prob * 2 + f])
+  for (size_t pb = 0; pb < p->prob_used.size(); ++pb) // realisations the plan reads (flagged by k_make_desc)
+    for (int f = 0; f < h->cfg.spacedim && p->prob_used[pb]; ++f)
+      if (!h->coef_set[pb * 2 + f])
         return fail(h, SLOD_ERR_STATE, "slod_plan_execute: coefficient field not set");
   (void)hipSetDevice(h->cfg.device);
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->stream;
@@ -725,6 +688,23 @@ int slod_plan_execute(slod_plan *p, double *d_basis, double *d_premult, void *hi
     return hip_fail(h, e, "slod_plan_execute");
   p->ran = true;
   ++p->n_exec;
+  return SLOD_OK;
+}
+
+int slod_plan_patch_layout(slod_plan *p, size_t k, int launch_order, slod_patch_info *info, uint32_t *plan_index)
+{
+  if (!p || !info)
+    return SLOD_ERR_ARGUMENT;
+  if (k >= p->n)
+    return fail(p->h, SLOD_ERR_ARGUMENT, "slod_plan_patch_layout: index out of range");
+  (void)hipSetDevice(p->h->cfg.device);
+  SlodPatchDesc    d;
+  const SlodPatchDesc *src = (launch_order && p->d_desc_bal ? p->d_desc_bal : p->d_desc) + k;
+  if (hipMemcpy(&d, src, sizeof(d), hipMemcpyDeviceToHost) != hipSuccess)
+    return hip_fail(p->h, hipGetLastError(), "slod_plan_patch_layout");
+  slod_desc_to_info(p->h, d, info);
+  if (plan_index)
+    *plan_index = d.plan_index;
   return SLOD_OK;
 }
 
@@ -1139,14 +1119,12 @@ int slod_plan_execute_allgather(slod_plan *p, slod_comm *c, double *d_basis_all,
     return fail(h, SLOD_ERR_ARGUMENT, "slod_plan_execute_allgather: needs two distinct streams and both slabs");
   if (p->n > patches_per_rank)
     return fail(h, SLOD_ERR_ARGUMENT, "slod_plan_execute_allgather: plan larger than a rank's slab");
-  for (size_t k = 0; k < p->n; ++k)
-    {
-      if (p->desc[k].out_off != (uint64_t)k * p->stride)
-        return fail(h, SLOD_ERR_STATE, "slod_plan_execute_allgather: the plan must use the uniform stride (NULL offsets)");
-      for (int f = 0; f < h->cfg.spacedim; ++f)
-        if (!h->coef_set[(size_t)p->desc[k].prob * 2 + f])
-          return fail(h, SLOD_ERR_STATE, "slod_plan_execute_allgather: coefficient field not set");
-    }
+  if (!p->uniform_stride)
+    return fail(h, SLOD_ERR_STATE, "slod_plan_execute_allgather: the plan must use the uniform stride (NULL offsets)");
+  for (size_t pb = 0; pb < p->prob_used.size(); ++pb)
+    for (int f = 0; f < h->cfg.spacedim && p->prob_used[pb]; ++f)
+      if (!h->coef_set[pb * 2 + f])
+        return fail(h, SLOD_ERR_STATE, "slod_plan_execute_allgather: coefficient field not set");
   (void)hipSetDevice(h->cfg.device);
   hipStream_t  cs = (hipStream_t)compute_stream, ns = (hipStream_t)comm_stream;
   const size_t slab = patches_per_rank * p->stride;

@@ -401,39 +401,104 @@ namespace
   }
 
   // ---- inputs produced on the device ----
-  __global__ void k_patch_info(const SlodGrid G, const uint32_t *ids, int n_ids, slod_patch_info *out)
+  // ---- the plan's patch descriptors, built on the device (create_patches + create_mesh_for_patch +
+  //      the index-set sizes, LOD.cc:122-244,770-858; one thread per patch of the plan).  Also: the plan's
+  //      maxima (atomicMax), the set of coefficient realisations it uses, an error flag for ids out of
+  //      range, and the cost key of the balanced launch order.
+  __global__ void k_make_desc(const SlodGrid G, SlodPlanBuild B)
   {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= n_ids)
+    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= B.n)
       return;
-    const int n = G.n_sub, s = G.spacedim;
-    int       cx, cy;
-    grid_centre(G, ids[k], cx, cy);
-    const Extent    e = grid_extent(G, cx, cy);
-    slod_patch_info info;
-    info.cx             = cx;
-    info.cy             = cy;
-    info.x0             = e.x0;
-    info.y0             = e.y0;
-    info.mx             = e.mx;
-    info.my             = e.my;
-    info.nx             = n * e.mx;
-    info.ny             = n * e.my;
-    info.side_domain[0] = e.x0 == 0;                // LOD.cc:830-843: id 0 on the domain boundary
-    info.side_domain[1] = e.x0 + e.mx == G.N;
-    info.side_domain[2] = e.y0 == 0;
-    info.side_domain[3] = e.y0 + e.my == G.N;
-    info.n_fine         = s * (info.nx + 1) * (info.ny + 1);
-    info.n_internal     = s * (info.nx - 1) * (info.ny - 1);
-    info.n_coarse       = s * e.mx * e.my;
+    const uint32_t gid = B.gids[k];
+    if ((uint64_t)gid >= (uint64_t)B.NP * (uint64_t)B.n_problems)
+      {
+        atomicOr(&B.acc->error, 1);
+        return;
+      }
+    const uint32_t prob = gid / (uint32_t)B.NP, pid = gid % (uint32_t)B.NP;
+    const int      n = G.n_sub, s = G.spacedim;
+    int            cx, cy;
+    grid_centre(G, pid, cx, cy);
+    Extent e = grid_extent(G, cx, cy);
+    const bool full = e.mx == 2 * G.oversampling + 1 && e.my == 2 * G.oversampling + 1;
+    SlodPatchDesc d;
+    memset(&d, 0, sizeof(d));
+    d.ox = e.x0 * n;
+    d.oy = e.y0 * n;
+    if (B.reuse_full && full && B.first_full >= 0)
+      {
+        // quirk Q1 (LOD.cc:354-362,446-450): later full patches copy the first one's matrix
+        int fx, fy;
+        grid_centre(G, (uint32_t)B.first_full, fx, fy);
+        const Extent f = grid_extent(G, fx, fy);
+        d.ox           = f.x0 * n;
+        d.oy           = f.y0 * n;
+      }
+    d.nx  = n * e.mx;
+    d.ny  = n * e.my;
+    d.mx  = e.mx;
+    d.my  = e.my;
+    d.ccx = cx - e.x0;
+    d.ccy = cy - e.y0;
+    const int sd0 = e.x0 == 0, sd1 = e.x0 + e.mx == G.N, sd2 = e.y0 == 0, sd3 = e.y0 + e.my == G.N; // LOD.cc:830-843
+    d.flags       = sd0 | (sd1 << 1) | (sd2 << 2) | (sd3 << 3);
+    const bool lod = !G.lod_stabilization || G.oversampling == 0 || e.mx * e.my == G.N * G.N; // LOD.cc:563-564
+    if (lod)
+      d.flags |= SLOD_F_LOD;
+    if (d.nx > d.ny)
+      {
+        d.flags |= SLOD_F_TRANSPOSED;
+        d.m = s * (d.ny - 1);
+        d.L = d.nx - 1;
+      }
+    else
+      {
+        d.m = s * (d.nx - 1);
+        d.L = d.ny - 1;
+      }
+    d.n_c = s * e.mx * e.my;
     // id-99 nodes, corners shared with an id-0 side included (LODtools.h:367-369)
-    const int side = !info.side_domain[0] + !info.side_domain[1];
-    int       nb   = (info.ny - 1) * side;
-    nb += info.side_domain[2] ? side : info.nx + 1;
-    nb += info.side_domain[3] ? side : info.nx + 1;
-    info.n_boundary = s * nb;
-    info.is_lod     = !G.lod_stabilization || G.oversampling == 0 || e.mx * e.my == G.N * G.N; // LOD.cc:563-564
-    out[k]          = info;
+    const int side = !sd0 + !sd1;
+    int       nb   = (d.ny - 1) * side;
+    nb += sd2 ? side : d.nx + 1;
+    nb += sd3 ? side : d.nx + 1;
+    d.n_b        = s * nb;
+    d.prob       = (int32_t)prob;
+    d.plan_index = (uint32_t)k;
+    d.out_off    = B.offsets ? B.offsets[k] : (uint64_t)k * B.stride;
+    B.desc[k]    = d;
+    const int nn = (d.nx + 1) * (d.ny + 1);
+    atomicMax(&B.acc->m_max, d.m);
+    atomicMax(&B.acc->L_max, d.L);
+    atomicMax(&B.acc->nc_max, d.n_c);
+    atomicMax(&B.acc->nb_max, lod ? 0 : d.n_b);
+    atomicMax(&B.acc->nn_max, nn);
+    atomicMax(&B.acc->out_size, (unsigned long long)d.out_off + (unsigned long long)s * s * nn);
+    B.prob_used[prob] = 1;
+    // cost key of the launch order: canonical solve flops + selection stage (rim patches are cheaper)
+    const double ni = (double)d.m * d.L, b = (double)d.m + s - 1;
+    B.cost[k]       = ni * (b * b + 3 * b) + 4.0 * d.n_c * ni * b + 200.0 * d.n_b * d.n_c;
+  }
+
+  // Balanced launch order on the device: rank of every patch by (cost descending, plan index ascending)
+  // -- a rank sort, O(n^2) coalesced reads, fine up to a few 10^4 patches -- then the snake over rows of
+  // n_cu blocks (see slod_plan_create).
+  __global__ void k_balance_order(const double *cost, const SlodPatchDesc *in, SlodPatchDesc *out, size_t n, int n_cu)
+  {
+    const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n)
+      return;
+    const double ck = cost[k];
+    size_t       r  = 0;
+    for (size_t j = 0; j < n; ++j)
+      {
+        const double cj = cost[j];
+        r += (cj > ck || (cj == ck && j < k)) ? 1 : 0;
+      }
+    const size_t row = r / (size_t)n_cu, col = r % (size_t)n_cu;
+    const size_t len = (size_t)n_cu < n - row * (size_t)n_cu ? (size_t)n_cu : n - row * (size_t)n_cu;
+    out[row * (size_t)n_cu + ((row & 1) ? len - 1 - col : col)] = in[k];
   }
 
   __global__ void k_sample_coefficient(int NE, const double *vals, int r, double *coef)
@@ -454,6 +519,66 @@ namespace
     coef[i]       = vals[idx];
   }
 } // namespace
+
+// slod_plan_create's device pass (declared in slod_host.h): descriptors, maxima, realisations in use,
+// balanced order.  Everything stays on the device except the 40-byte summary and the used-problem map.
+hipError_t slod_build_descriptors(const slod_handle *h, const uint32_t *gids, size_t n, const uint64_t *offsets, size_t stride,
+                                  int n_cu, bool balance, SlodPatchDesc *d_desc, SlodPatchDesc *d_desc_bal, SlodPlanSummary *sum,
+                                  std::vector<char> *prob_used)
+{
+  SlodPlanBuild B;
+  memset(&B, 0, sizeof(B));
+  uint32_t *d_gids = nullptr;
+  uint64_t *d_offs = nullptr;
+  hipError_t e = hipMalloc((void **)&d_gids, n * sizeof(uint32_t));
+  if (e == hipSuccess && offsets)
+    e = hipMalloc((void **)&d_offs, n * sizeof(uint64_t));
+  if (e == hipSuccess)
+    e = hipMalloc((void **)&B.cost, n * sizeof(double));
+  if (e == hipSuccess)
+    e = hipMalloc((void **)&B.acc, sizeof(SlodPlanSummary));
+  if (e == hipSuccess)
+    e = hipMalloc((void **)&B.prob_used, (size_t)h->cfg.n_problems);
+  if (e == hipSuccess)
+    e = hipMemsetAsync(B.acc, 0, sizeof(SlodPlanSummary), h->stream);
+  if (e == hipSuccess)
+    e = hipMemsetAsync(B.prob_used, 0, (size_t)h->cfg.n_problems, h->stream);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(d_gids, gids, n * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess && offsets)
+    e = hipMemcpyAsync(d_offs, offsets, n * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess)
+    {
+      B.gids       = d_gids;
+      B.offsets    = d_offs;
+      B.n          = n;
+      B.stride     = stride;
+      B.NP         = h->NP;
+      B.n_problems = h->cfg.n_problems;
+      B.reuse_full = h->cfg.constant_coefficients;
+      B.first_full = h->first_full;
+      B.desc       = d_desc;
+      hipLaunchKernelGGL(k_make_desc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, slod_grid_of(h), B);
+      e = hipGetLastError();
+    }
+  if (e == hipSuccess && balance && d_desc_bal)
+    {
+      hipLaunchKernelGGL(k_balance_order, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, B.cost, d_desc, d_desc_bal, n,
+                         n_cu);
+      e = hipGetLastError();
+    }
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(sum, B.acc, sizeof(SlodPlanSummary), hipMemcpyDeviceToHost, h->stream);
+  prob_used->assign((size_t)h->cfg.n_problems, 0);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(prob_used->data(), B.prob_used, (size_t)h->cfg.n_problems, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess)
+    e = hipStreamSynchronize(h->stream);
+  for (void *q : {(void *)d_gids, (void *)d_offs, (void *)B.cost, (void *)B.acc, (void *)B.prob_used})
+    if (q)
+      (void)hipFree(q);
+  return e;
+}
 
 #pragma GCC visibility push(default)
 extern "C" {
@@ -658,34 +783,34 @@ int slod_device_patch_layout(slod_handle *h, const uint32_t *patch_ids, size_t n
     return SLOD_ERR_ARGUMENT;
   if (n == 0)
     return SLOD_OK;
-  for (size_t k = 0; k < n; ++k)
-    if (patch_ids[k] >= (uint32_t)h->NP)
-      return slod_fail(h, SLOD_ERR_ARGUMENT, "slod_device_patch_layout: patch id out of range");
   if (const int rc = slod_ensure_device(h))
     return rc;
   (void)hipSetDevice(h->cfg.device);
-  uint32_t        *d_ids = nullptr;
-  slod_patch_info *d_out = nullptr;
-  hipError_t       e = hipMalloc((void **)&d_ids, n * sizeof(uint32_t));
+  // the SAME kernel that builds a plan's descriptors (k_make_desc), read back and reported as
+  // slod_patch_info; ids of problem 0 (< num_patches): the id range check runs in the kernel
+  SlodPatchDesc *d_desc = nullptr;
+  hipError_t     e = hipMalloc((void **)&d_desc, n * sizeof(SlodPatchDesc));
+  SlodPlanSummary   sum;
+  std::vector<char> used;
+  memset(&sum, 0, sizeof(sum));
   if (e == hipSuccess)
-    e = hipMalloc((void **)&d_out, n * sizeof(slod_patch_info));
-  if (e == hipSuccess)
-    e = hipMemcpyAsync(d_ids, patch_ids, n * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream);
-  if (e == hipSuccess)
+    e = slod_build_descriptors(h, patch_ids, n, nullptr, 0, 1, false, d_desc, nullptr, &sum, &used);
+  std::vector<SlodPatchDesc> desc(n);
+  if (e == hipSuccess && !sum.error)
+    e = hipMemcpy(desc.data(), d_desc, n * sizeof(SlodPatchDesc), hipMemcpyDeviceToHost);
+  if (d_desc)
+    (void)hipFree(d_desc);
+  if (e != hipSuccess)
+    return slod_hip_fail(h, e, "slod_device_patch_layout");
+  if (sum.error)
+    return slod_fail(h, SLOD_ERR_ARGUMENT, "slod_device_patch_layout: patch id out of range");
+  for (size_t k = 0; k < n; ++k)
     {
-      hipLaunchKernelGGL(k_patch_info, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, slod_grid_of(h), d_ids,
-                         (int)n, d_out);
-      e = hipGetLastError();
+      if (desc[k].prob != 0)
+        return slod_fail(h, SLOD_ERR_ARGUMENT, "slod_device_patch_layout: patch id out of range");
+      slod_desc_to_info(h, desc[k], &out[k]);
     }
-  if (e == hipSuccess)
-    e = hipMemcpyAsync(out, d_out, n * sizeof(slod_patch_info), hipMemcpyDeviceToHost, h->stream);
-  if (e == hipSuccess)
-    e = hipStreamSynchronize(h->stream);
-  if (d_ids)
-    (void)hipFree(d_ids);
-  if (d_out)
-    (void)hipFree(d_out);
-  return e == hipSuccess ? SLOD_OK : slod_hip_fail(h, e, "slod_device_patch_layout");
+  return SLOD_OK;
 }
 
 int slod_sample_coefficient(slod_handle *h, uint32_t problem, int field, const double *d_vals, int r)

@@ -57,4 +57,45 @@ inline SlodGrid slod_grid_of(const slod_handle *h)
   g.lod_stabilization = h->cfg.lod_stabilization;
   return g;
 }
+// plan construction on the device (slod_global.hip: k_make_desc, k_balance_order)
+struct SlodPlanSummary
+{
+  int32_t            m_max, L_max, nc_max, nb_max, nn_max, error;
+  unsigned long long out_size;
+};
+struct SlodPlanBuild
+{
+  const uint32_t  *gids;
+  const uint64_t  *offsets; // may be null: uniform stride
+  size_t           n, stride;
+  int32_t          NP, n_problems, reuse_full, first_full;
+  SlodPatchDesc   *desc;
+  double          *cost;
+  SlodPlanSummary *acc;
+  char            *prob_used;
+};
+// descriptor -> public patch layout (slod_plan_patch_layout, slod_device_patch_layout)
+inline void slod_desc_to_info(const slod_handle *h, const SlodPatchDesc &d, slod_patch_info *info)
+{
+  const int n = h->cfg.n_subdivisions, s = h->cfg.spacedim;
+  *info       = slod_patch_info();
+  info->mx    = d.mx;
+  info->my    = d.my;
+  info->nx    = d.nx;
+  info->ny    = d.ny;
+  info->x0    = d.ox / n; // (under the reuse quirk Q1 the coefficient origin is the first full patch's)
+  info->y0    = d.oy / n;
+  info->cx    = info->x0 + d.ccx;
+  info->cy    = info->y0 + d.ccy;
+  for (int k = 0; k < 4; ++k)
+    info->side_domain[k] = (d.flags >> k) & 1;
+  info->n_fine     = s * (d.nx + 1) * (d.ny + 1);
+  info->n_internal = s * (d.nx - 1) * (d.ny - 1);
+  info->n_boundary = d.n_b;
+  info->n_coarse   = d.n_c;
+  info->is_lod     = (d.flags & SLOD_F_LOD) ? 1 : 0;
+}
+hipError_t slod_build_descriptors(const slod_handle *h, const uint32_t *gids, size_t n, const uint64_t *offsets, size_t stride,
+                                  int n_cu, bool balance, SlodPatchDesc *d_desc, SlodPatchDesc *d_desc_bal, SlodPlanSummary *sum,
+                                  std::vector<char> *prob_used);
 #endif

@@ -87,6 +87,7 @@ def load():
     lib.slod_plan_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.slod_plan_profile.argtypes = [vp, C.c_int]
     lib.slod_plan_status.argtypes = [vp]
+    lib.slod_plan_patch_layout.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(PatchInfo), u32p]
     lib.slod_plan_diagnostics.argtypes = [vp, C.POINTER(PatchDiag), C.c_size_t]
     lib.slod_compute_basis.argtypes = [vp, u32p, C.c_size_t, dp, dp, u64p]
     lib.slod_comm_last_error.restype = C.c_char_p
@@ -207,6 +208,12 @@ class Plan:
 
     def status(self):
         self.slod._check(self.lib.slod_plan_status(self.p))
+
+    def patch_layout(self, k, launch_order=False):
+        """(PatchInfo, plan_index) of the k-th descriptor the kernels launch with (device read-back)."""
+        info, idx = PatchInfo(), C.c_uint32()
+        self.slod._check(self.lib.slod_plan_patch_layout(self.p, k, 1 if launch_order else 0, C.byref(info), C.byref(idx)))
+        return info, idx.value
 
     def diagnostics(self):
         """[(patch k, component d)] -> PatchDiag of the last execute."""

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SLOD_ABI_VERSION 4
+#define SLOD_ABI_VERSION 5
 
 typedef enum
 {
@@ -135,6 +135,11 @@ int slod_plan_profile(slod_plan *p, int depth);
  * slod_plan_execute; slod_plan_execute_allgather records none: SLOD_ERR_STATE after it);
  * synchronises.  ms[0] assemble, ms[1] patch solve, ms[2] selection */
 int slod_plan_kernel_ms(slod_plan *p, float ms[3]);
+/* The k-th patch descriptor the plan's kernels LAUNCH with, read back from the device (the descriptors
+ * are produced by a device kernel from the grid scalars: create_patches + create_mesh_for_patch,
+ * LOD.cc:122-244,770-858).  launch_order = 0: the caller's order; 1: the balanced launch order
+ * (plan_index then tells which entry of the caller's list sits at launch position k). */
+int slod_plan_patch_layout(slod_plan *p, size_t k, int launch_order, slod_patch_info *info, uint32_t *plan_index);
 /* numerical status of the last execute (0 or SLOD_ERR_NUMERIC); synchronises. */
 int slod_plan_status(slod_plan *p);
 

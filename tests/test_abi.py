@@ -16,7 +16,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 18
     for n in names:
         assert hasattr(lib, n), "missing export " + n
-    assert lib.slod_abi_version() == 4
+    assert lib.slod_abi_version() == 5
 
 
 def test_release_library_exports_exactly_the_header():

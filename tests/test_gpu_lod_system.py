@@ -196,6 +196,48 @@ def test_device_patch_layout_matches_host_and_golden():
             assert bytes(di) == bytes(hi), (kw, pid)
 
 
+def test_plan_descriptors_are_device_built_and_match_golden():
+    """The descriptors a plan LAUNCHES with (slod_plan_patch_layout: read back from the device, where
+    k_make_desc built them) reproduce tests/create_patch_01.output (32 x 32 cells, oversampling 4,
+    Morton order) and the host index calculus; the balanced launch order is a permutation of the
+    caller's list with non-increasing cost along the rank order; bad ids are rejected by the kernel."""
+    import slod_amd
+    # golden geometry (oversampling 4: 81 coarse dofs, beyond what the kernels run, so no plan): the
+    # descriptor kernel k_make_desc through slod_device_patch_layout
+    g = slod_amd.Slod(nref=5, n_sub=2, oversampling=4)
+    ids = np.arange(g.num_patches, dtype=np.uint32)
+    dinfo = g.device_patch_layout(ids)
+    lines = open(os.path.join(GOLDEN, "reference", "create_patch_01.output")).read().strip().split("\n")[1:]
+    for ln in lines:
+        pid = int(ln.split(":")[0][2:])
+        cnt = int(ln.split("{")[1].split("}")[0])
+        assert dinfo[pid].mx * dinfo[pid].my == cnt
+    # the same 32 x 32 grid at oversampling 3 as a plan: what the kernels launch with
+    g = slod_amd.Slod(nref=5, n_sub=2, oversampling=3)
+    plan = g.plan(ids)
+    dinfo = g.device_patch_layout(ids)
+    for pid in ids:
+        info, idx = plan.patch_layout(int(pid))
+        assert bytes(info) == bytes(dinfo[pid]) == bytes(g.patch_layout(int(pid))) and idx == pid
+    for kw in (dict(nref=3, n_sub=4, oversampling=2, spacedim=2), dict(n_cells=6, n_sub=3, oversampling=1),
+               dict(nref=2, n_sub=2, oversampling=2, stabilize=0)):
+        g2 = slod_amd.Slod(**kw)
+        ids2 = np.arange(g2.num_patches, dtype=np.uint32)[::-1].copy()
+        plan2 = g2.plan(ids2)
+        seen = set()
+        for k, pid in enumerate(ids2):
+            info, idx = plan2.patch_layout(k)
+            assert bytes(info) == bytes(g2.patch_layout(int(pid))), (kw, pid)
+            assert idx == k
+            linfo, lidx = plan2.patch_layout(k, launch_order=True)
+            seen.add(lidx)
+            assert bytes(linfo) == bytes(g2.patch_layout(int(ids2[lidx])))
+        assert seen == set(range(len(ids2)))
+    with pytest.raises(slod_amd.SlodError) as e:
+        g.plan(np.array([0, g.num_patches], dtype=np.uint32))
+    assert e.value.code == -1
+
+
 def test_device_coefficient_sampling_matches_reference_formula(so):
     """problem_parameter::value (Diffusion.h:40-53) sampled on the device at the points of
     quadrature_fine == the oracle's host evaluation of the same glibc rand() field, bit for bit;
