@@ -108,6 +108,56 @@ def cpu_baseline(cfg_kw, fields, n_full, every=1):
             "value_1thread": len(sub) / t1}
 
 
+def lod_system_leg(slod, torch, dev, basis, premult, stride):
+    """Device times of the SURVEY 8(f) rows on the bench configuration: global LOD matrix and right-hand
+    side from the (phi, psi) slab just built (LOD.cc:860-973,982), coarse CG solve (:990-998),
+    reconstruction u_h = C u_H (:1251) and the fine FEM reference solve (:1004-1094), f = 1.  Achieved
+    GB/s against the algorithmic bytes each kernel must move (stated per row)."""
+    s, NP, NE = slod.spacedim, slod.num_patches, slod.NE
+    cap = slod.lod_row_capacity()
+    rows = np.arange(NP, dtype=np.uint32)
+    nfine = (NE + 1) * (NE + 1) * s
+
+    def timed(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3, out
+
+    vals = torch.zeros(NP * cap * s * s, dtype=torch.float64, device=dev)
+    cols = torch.zeros(NP * cap, dtype=torch.int32, device=dev)
+    frhs = torch.zeros(nfine, dtype=torch.float64, device=dev)
+    rhs = torch.zeros(NP * s, dtype=torch.float64, device=dev)
+    u = torch.zeros(NP * s, dtype=torch.float64, device=dev)
+    fine = torch.zeros(nfine, dtype=torch.float64, device=dev)
+    ufem = torch.zeros(nfine, dtype=torch.float64, device=dev)
+    slab_bytes = 8.0 * NP * stride
+    t_mat, _ = timed(lambda: slod.lod_matrix(rows, basis.data_ptr(), premult.data_ptr(), stride, vals.data_ptr(), cols.data_ptr()))
+    slod.fem_rhs(None, frhs.data_ptr())
+    t_rhs, _ = timed(lambda: slod.lod_rhs(rows, basis.data_ptr(), stride, frhs.data_ptr(), rhs.data_ptr()))
+    t_sol, (it_lod, res_lod) = timed(lambda: slod.lod_solve(vals.data_ptr(), cols.data_ptr(), rhs.data_ptr(), u.data_ptr(), 1e-10, 20000), reps=1)
+    t_rec, _ = timed(lambda: slod.lod_reconstruct(basis.data_ptr(), stride, u.data_ptr(), fine.data_ptr()))
+    t_fem, (it_fem, res_fem) = timed(lambda: slod.fem_solve(frhs.data_ptr(), ufem.data_ptr(), 1e-10, 100000), reps=1)
+    err = float((fine - ufem).norm() / ufem.norm())
+    gbps = lambda nbytes, ms: nbytes / (ms * 1e-3) / 1e9
+    return {
+        "lod_matrix_ms": t_mat, "lod_matrix_GBps": gbps(2 * slab_bytes + 8.0 * NP * cap * (s * s + 0.5), t_mat),
+        "lod_rhs_ms": t_rhs, "lod_rhs_GBps": gbps(slab_bytes + 8.0 * nfine, t_rhs),
+        "lod_solve": {"iters": it_lod, "ms": t_sol, "rel_residual": res_lod, "preconditioner": "Jacobi",
+                      "GBps": gbps(it_lod * 8.0 * NP * cap * (s * s + 0.5), t_sol)},
+        "reconstruct_ms": t_rec, "reconstruct_GBps": gbps(slab_bytes + 8.0 * nfine, t_rec),
+        "fem_solve": {"iters": it_fem, "ms": t_fem, "rel_residual": res_fem, "preconditioner": "Jacobi",
+                      "unknowns": nfine, "GBps": gbps(it_fem * 8.0 * nfine * (9 * s * s + 6), t_fem)},
+        "rel_l2_lod_vs_fem": err,
+        "bytes_model": "lod_matrix: (phi,psi) slab once + the block rows written; lod_rhs/reconstruct: phi slab + fine vector; "
+                       "CG: per iteration the block rows (values + column ids) resp. the 9-point stencil planes + 6 vectors",
+        "hbm_peak_GBps": PEAK_HBM_GBPS,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,6 +165,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the two-stream measurement")
+    ap.add_argument("--no-lod-system", action="store_true", help="skip the timing of the consumers of (phi, psi)")
     ap.add_argument("--dist", default="D1e4", choices=["D100", "D1e4"])
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS),
                     help="BASELINE.json configuration (C2 = the headline metric's; C3, C4: extra lines)")
@@ -210,6 +261,12 @@ def main():
         plan2.status()
         assert torch.equal(basis2, basis) and torch.equal(premult2, premult)
         pipelined = {"streams": 2, "value": n_local * args.steps / ep, "ms_per_step": ep / args.steps * 1e3}
+
+    # outside the metric: the consumers of (phi, psi) at this configuration's scale:
+    # A_LOD = C^T (A C), C^T f, coarse solve, reconstruction, fine FEM reference solve
+    lod_system = None
+    if world == 1 and not args.no_lod_system and n_prob == 1:
+        lod_system = lod_system_leg(slod, torch, dev, basis, premult, plan.stride)
 
     # the exchange step (outside the metric): RCCL all-gather of the (phi,psi) slabs
     allgather_ms = None
@@ -316,6 +373,7 @@ def main():
                          "hbm_frac": nbytes / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBPS},
             "allgather_ms": allgather_ms,
             "pipelined": pipelined,
+            "lod_system": lod_system,
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(CFG, fields[probs[0]], NP, every={"C2": 1, "C3": 256, "C4": 8}[args.config])
