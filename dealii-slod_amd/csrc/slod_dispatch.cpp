@@ -64,9 +64,7 @@ bool slod_choose_solver(int S, int n_sub, int m_max, int L_max, int nc_max, int 
       c.lds           = slod_solve_nd_lds_bytes(nd_nv, m_max, nc_max);
       c.v_patch_elems = slod_solve_nd_scratch(nd_nv, m_max, L_max, nc_max);
       c.fuse_assemble = t.fuse_assemble ? 1 : 0;
-      c.fuse_select   = (t.fuse_select && lds_sel <= 64 * 1024) ? 1 : 0;
-      if (c.fuse_select && lds_sel > c.lds)
-        c.lds = lds_sel;
+      c.fuse_select   = 0; // 512-thread workgroups: the selection stage is its own launch
     }
   else if (mf_fits && (t.solver == SLOD_K_MF || (t.solver == 0 && !tw_fits && !ws_fits)))
     {

@@ -2,6 +2,8 @@
 // slod_solve_nd.hip.h, the NV = 8 instantiations in slod_solve_nd8a/b.hip (one object each: build time).
 #include "slod_solve_nd.hip.h"
 
+#include <algorithm>
+
 // ---- host side -------------------------------------------------------------------------------
 int slod_solve_nd_cell(int S, int n_sub, int m_max, int L_max)
 {
@@ -22,10 +24,13 @@ size_t slod_solve_nd_scratch(int nv, int m_max, int L_max, int nc_max)
 
 size_t slod_solve_nd_lds_bytes(int nv, int m_max, int nc_max)
 {
-  // per wave: pivot row + ring couplings (condensation, skeleton) or the factor lines (first phase)
-  const int    T = slod_solve_ws_tile(m_max);
-  const size_t a = (size_t)4 * (8 * T + 4 * nv * 4 + ((nv - 1) * (nv - 1) > 32 ? 24 * (4 * nv + 2) : 0)), b = (size_t)4 * (64 / (nv + 1) + 1) * 2 * (nv + 1);
-  return (a > b ? a : b) * sizeof(double);
+  // the largest of: SIMT phases (per wave: pivot row, ring couplings, parked rows), factor lines,
+  // skeleton front (three m x m blocks, edge block, coupling / right-hand-side block, pivot row)
+  const int    T = slod_solve_ws_tile(m_max), MP = 8 * T, NW = ND_WAVES, ncp = (nc_max + 15) & ~15;
+  const size_t a = (size_t)NW * (MP + 4 * nv * 4 + ((nv - 1) * (nv - 1) > 32 ? 24 * (4 * nv + 2) : 0));
+  const size_t b = (size_t)NW * (64 / (nv + 1) + 1) * 2 * (nv + 1);
+  const size_t c = (size_t)3 * MP * (MP + 1) + 32 * 33 + (size_t)32 * (2 * MP + ncp) + MP;
+  return std::max(a, std::max(b, c)) * sizeof(double);
 }
 
 hipError_t slod_launch_nd8a(int T, const SlodKernelArgs &a, int n_patches, size_t lds, hipStream_t st);

@@ -21,10 +21,12 @@
 #ifndef SLOD_SOLVE_ND_HIP_H
 #define SLOD_SOLVE_ND_HIP_H
 #include "slod_assemble.hip.h"
-#include "slod_select.hip.h"
 
 #ifndef ND_GB
 #define ND_GB 3 // rows of a cell factor per scalar-load batch
+#endif
+#ifndef ND_WAVES
+#define ND_WAVES 8 // 512-thread workgroups, two per CU: 80 KB of LDS hold the skeleton front of a patch
 #endif
 #ifndef ND_PHASES
 #define ND_PHASES 0xffff // development switch (tools/): compile only some phases of k_solve_nd
@@ -39,7 +41,7 @@ namespace
   struct NdLayout
   {
     int    cblk;                                   // doubles per cell factor block
-    size_t fac, cmat, gvec, aee, r, y, yg, t, b, w, zs, p, total;
+    size_t fac, cmat, gvec, y, yg, w, zs, p, total;
   };
   __host__ __device__ inline NdLayout nd_layout(int nv, int T, int m_max, int L_max, int nc_max)
   {
@@ -52,15 +54,11 @@ namespace
     l.fac        = take((size_t)ncell * l.cblk);
     l.cmat       = take((size_t)ncell * ring * ring);
     l.gvec       = take((size_t)ncell * ring);
-    l.aee        = take((size_t)Ca * NEP * NEP);
-    l.r          = take((size_t)Ca * NEP * 2 * MP);
-    l.y          = take((size_t)Ca * NEP * 2 * MP);
-    l.yg         = take((size_t)Ca * NEP * nc_max);
-    l.t          = take((size_t)Ca * MP * MP);
-    l.b          = take((size_t)Ca * MP * MP);
-    l.w          = take((size_t)Ca * MP * MP);
-    l.zs         = take((size_t)Ca * MP * nc_max);
-    l.p          = take((size_t)MP * MP);
+    l.y          = take((size_t)Ca * NEP * 2 * MP);  // Y_H of every strip (edge back substitution)
+    l.yg         = take((size_t)Ca * NEP * nc_max);  // Y_G
+    l.w          = take((size_t)Ca * MP * MP);       // W_a = V_a B_a of every line (backward sweep)
+    l.zs         = take((size_t)Ca * MP * nc_max);   // Z_a
+    l.p          = take(8);
     l.total      = o;
     return l;
   }
@@ -362,11 +360,11 @@ namespace
   const size_t         xline = (size_t)A.m_max * ncg;                                                                  \
   const NdLayout       lay = nd_layout(NV, T, A.m_max, A.L_max, A.nc_max);                                             \
   double *const        facg = ws + lay.fac, *const cmat = ws + lay.cmat, *const gvec = ws + lay.gvec;                  \
-  double *const        aee = ws + lay.aee, *const rg = ws + lay.r, *const yh = ws + lay.y, *const yg = ws + lay.yg;    \
-  double *const        tm = ws + lay.t, *const bm = ws + lay.b, *const wm = ws + lay.w, *const zs = ws + lay.zs;       \
-  double *const        pm = ws + lay.p;                                                                                \
-  (void)nc; (void)n; (void)ncell; (void)nH; (void)NE; (void)xline; (void)facg; (void)cmat; (void)gvec; (void)aee;      \
-  (void)rg; (void)yh; (void)yg; (void)tm; (void)bm; (void)wm; (void)zs; (void)pm; (void)Ca; (void)Cb; (void)npx;       \
+  double *const        yh = ws + lay.y, *const yg = ws + lay.yg;                                                       \
+  double *const        wm = ws + lay.w, *const zs = ws + lay.zs;                                                       \
+  double *const        pm = ws + lay.p; /* one dead word: store target of idle lanes */                               \
+  (void)nc; (void)n; (void)ncell; (void)nH; (void)NE; (void)xline; (void)facg; (void)cmat; (void)gvec;                 \
+  (void)yh; (void)yg; (void)wm; (void)zs; (void)pm; (void)Ca; (void)Cb; (void)npx;                                     \
   /* A[(l,i),(l+dl,i+o)], both nodes interior to the patch */                                                          \
   auto cpl = [&](int l, int i, int dl, int o) -> double {                                                              \
     return coupling<1>(st, A.nn_max, npx, tr, m, l, i, dl, o);                                                         \
@@ -386,15 +384,22 @@ namespace
     l = side == 0 ? l0 - 1 : (side == 1 ? l0 + NV - 1 : l0 + off);                                                     \
     i = side < 2 ? i0 - 1 + off : (side == 2 ? i0 - 1 : i0 + NV - 1);                                                  \
   };                                                                                                                   \
-  (void)cpl; (void)live; (void)xrow; (void)own_col; (void)ring_node;
+  /* inverse of ring_node: position of skeleton node (l, i) in the ring of cell (a, b) */                              \
+  auto ring_index = [&](int a, int b, int l, int i) {                                                                  \
+    const int l0 = a * NV, i0 = b * NV;                                                                                \
+    return l == l0 - 1 ? i - (i0 - 1)                                                                                  \
+                       : (l == l0 + NV - 1 ? NV + 1 + i - (i0 - 1) : (i == i0 - 1 ? 2 * NV + 2 + l - l0 : 3 * NV + 1 + l - l0)); \
+  };                                                                                                                   \
+  (void)cpl; (void)live; (void)xrow; (void)own_col; (void)ring_node; (void)ring_index;
 
   template <int NV, int T>
-  __global__ __launch_bounds__(256, 4) void k_solve_nd(const SlodKernelArgs Akern)
+  __global__ __launch_bounds__(64 * ND_WAVES, 4) void k_solve_nd(const SlodKernelArgs Akern)
   {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     (void)Akern; // read through nd_args()
     constexpr int       N1 = NV - 1, NR = N1 * N1, RING = 4 * NV, MP = 8 * T, NEP = 32, MP2 = 2 * MP;
     constexpr int       KTM = MP / 4; // k-steps over a line
+    constexpr int       NW = ND_WAVES, NT = 64 * NW; // waves / threads of the workgroup
     const int           tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = tid & 63;
     const int           lane_ = lane;
     // LDS: per wave a pivot row [MP] and the ring couplings of the wave's current cell [RING][4]
@@ -421,7 +426,7 @@ namespace
     // ------------------------------ stencil planes of the patch --------------------------------
     if ((ND_PHASES & 512) && A.fuse_assemble)
       {
-        for (int node = tid; node < npx * (d.ny + 1); node += 256)
+        for (int node = tid; node < npx * (d.ny + 1); node += NT)
           assemble_node<1>(A, d, blockIdx.x, node);
         __syncthreads();
       }
@@ -440,7 +445,7 @@ namespace
       {
         constexpr int GL = NV + 1, CPW = 64 / GL; // lanes per cell, cells per wave
         double       *lb = smem + wave * ((CPW + 1) * 2 * GL); // (one spare line: the lanes past the last group)
-        for (int c0 = 0; c0 < ncell; c0 += 4 * CPW)
+        for (int c0 = 0; c0 < ncell; c0 += NW * CPW)
           {
             const int  grp = lane / GL, q0 = lane - grp * GL;
             const int  c = c0 + wave * CPW + grp;
@@ -537,10 +542,10 @@ namespace
         nd_prefetch_1k(facg + (size_t)wave * lay.cblk + 4 * ND_BST, lane_, pf);
       }
     if (ND_PHASES & 4)
-    for (int c = wave; c < ncell; c += 4)
+    for (int c = wave; c < ncell; c += NW)
       {
         const int     a = c / Cb, b = c - a * Cb, l0 = a * NV, i0 = b * NV;
-        const double *fac = facg + (size_t)c * lay.cblk, *fac_next = facg + (size_t)(c + 4 < ncell ? c + 4 : c) * lay.cblk;
+        const double *fac = facg + (size_t)c * lay.cblk, *fac_next = facg + (size_t)(c + NW < ncell ? c + NW : c) * lay.cblk;
         // opaque copy of the lane id: everything derived from it is recomputed per cell instead of
         // being hoisted out of the loop and spilled (LICM would keep ~100 per-lane values alive)
         int lane = lane_;
@@ -635,54 +640,13 @@ namespace
     stamp(3);
     {
     ND_LOCALS
-    // ------------------------------ skeleton matrices: direct couplings -------------------------
-    // T_a (line a x line a), B_a (line a x line a+1, filled by the cells only), A_EE / A_EH of every
-    // strip, and the right-hand sides of all skeleton nodes (rows of X)
+    // ------------------------------ right-hand sides of the skeleton nodes -----------------------
+    // rows of X of the skeleton nodes <- P^T rows (LODtools.h:24-67: (h^2/4) {1,2,4}) plus the condensed
+    // right-hand sides of the (at most four) cells around the node, added in a fixed order
     if (ND_PHASES & 2)
     {
-    for (int idx = tid; idx < nH * MP * MP; idx += 256)
-      {
-        const int a = idx / (MP * MP), rem = idx - a * MP * MP, i = rem / MP, j = rem - i * MP;
-        double    v = 0.0;
-        if (i < m && j < m && j - i <= 1 && i - j <= 1)
-          v = cpl(a * NV + NV - 1, i, 0, j - i);
-        tm[idx] = v;
-        bm[idx] = 0.0;
-      }
-    for (int idx = tid; idx < Ca * NEP * NEP; idx += 256)
-      {
-        const int a = idx / (NEP * NEP), rem = idx - a * NEP * NEP, e1 = rem / NEP, e2 = rem - e1 * NEP;
-        double    v = 0.0;
-        if (e1 < NE && e2 < NE)
-          {
-            const int b1 = e1 / N1, q1 = e1 - b1 * N1, b2 = e2 / N1, q2 = e2 - b2 * N1;
-            if (b1 == b2 && q2 - q1 <= 1 && q1 - q2 <= 1)
-              v = cpl(a * NV + q1, b1 * NV + NV - 1, q2 - q1, 0);
-          }
-        aee[idx] = v;
-      }
-    for (int idx = tid; idx < Ca * NEP * MP2; idx += 256)
-      {
-        const int a = idx / (NEP * MP2), rem = idx - a * NEP * MP2, e = rem / MP2, h = rem - e * MP2;
-        double    v = 0.0;
-        if (e < NE)
-          {
-            const int be = e / N1, q = e - be * N1, ie = be * NV + NV - 1;
-            const int top = h >= MP, pos = top ? h - MP : h;
-            if (pos < m && pos - ie <= 1 && ie - pos <= 1)
-              {
-                if (!top && q == 0 && a > 0)
-                  v = cpl(a * NV, ie, -1, pos - ie);
-                if (top && q == N1 - 1 && a < Ca - 1)
-                  v = cpl(a * NV + q, ie, 1, pos - ie);
-              }
-          }
-        rg[idx] = v;
-      }
-    {
-      // rows of X of the skeleton nodes <- P^T rows (LODtools.h:24-67: (h^2/4) {1,2,4})
       const int nsk = nH * m + Ca * NE;
-      for (int idx = tid; idx < nsk * nc; idx += 256)
+      for (int idx = tid; idx < nsk * nc; idx += NT)
         {
           const int s = idx / nc, k = idx - s * nc;
           int       l, i;
@@ -699,294 +663,310 @@ namespace
               i = be * NV + NV - 1;
             }
           const int ix = tr ? l + 1 : i + 1, iy = tr ? i + 1 : l + 1;
-          xrow(l, i)[k] = A.scale * pt_weight<1>(d, n, A.quirk, ix, iy, 0, k);
+          double    v  = A.scale * pt_weight<1>(d, n, A.quirk, ix, iy, 0, k);
+          const int a_lo = l / NV, a_hi = (l + 1) / NV, b_lo = i / NV, b_hi = (i + 1) / NV; // cells whose ring holds the node
+          for (int a = a_lo; a <= a_hi && a < Ca; ++a)
+            for (int b = b_lo; b <= b_hi && b < Cb; ++b)
+              if (own_col(a, b) == k)
+                v += gvec[(size_t)(a * Cb + b) * RING + ring_index(a, b, l, i)];
+          xrow(l, i)[k] = v;
         }
     }
+    __syncthreads();
     }
-    __syncthreads(); // factors, initial skeleton matrices and right-hand sides are in the scratch slot
 
-    }
     stamp(4);
     {
     ND_LOCALS
-    // ------------------------------ scatter of the cell matrices --------------------------------
-    // cells of one colour (a mod 2, b mod 2) never touch the same skeleton entry: four plain
-    // read-modify-write passes in a fixed order (deterministic sums, no atomics)
+    // ------------------------------ skeleton: strip by strip, in LDS ----------------------------
+    // Frontal sweep over the cell rows.  LDS holds the front only: three m x m blocks (T of the line
+    // below the strip, the coupling B between the two lines of the strip, T of the line above), the
+    // edge-set matrix of the strip and its coupling / right-hand-side block.  Per strip: gather the
+    // cell matrices (global, read once), invert the edge block (one wave, registers), Y = V_EE R and
+    // the Schur complement R_H^T Y straight from the accumulators (the D fragment of a 16-row tile IS
+    // the B fragment of k-steps 4 ti .. 4 ti + 3), eliminate the finished line below (Gauss-Jordan in
+    // one wave, W = V B and P = B^T W again accumulator to operand).  Only Y, W and Z leave the CU.
     if (ND_PHASES & 8)
-    for (int colour = 0; colour < 4; ++colour)
       {
-        const int pa = colour >> 1, pb = colour & 1;
-        const int na = (Ca - pa + 1) / 2, nb = (Cb - pb + 1) / 2;
-        for (int idx = tid; idx < na * nb * RING * RING; idx += 256)
-          {
-            const int cc = idx / (RING * RING), ent = idx - cc * RING * RING;
-            const int a = 2 * (cc / nb) + pa, b = 2 * (cc % nb) + pb, c = a * Cb + b;
-            const int j1 = ent / RING, j2 = ent - j1 * RING;
-            int       l1, i1, l2, i2;
-            ring_node(a, b, j1, l1, i1);
-            ring_node(a, b, j2, l2, i2);
-            if (!live(l1, i1) || !live(l2, i2))
-              continue;
-            const int    s1 = ring_side<NV>(j1), s2 = ring_side<NV>(j2);
-            const double v = cmat[(size_t)c * RING * RING + ent];
-            if (s1 < 2 && s2 < 2)
-              {
-                if (s1 == s2)
-                  tm[(size_t)(s1 == 0 ? a - 1 : a) * MP * MP + i1 * MP + i2] += v;
-                else if (s1 == 0)
-                  bm[(size_t)(a - 1) * MP * MP + i1 * MP + i2] += v;
-              }
-            else if (s1 >= 2 && s2 >= 2)
-              {
-                const int e1 = (s1 == 2 ? b - 1 : b) * N1 + (l1 - a * NV), e2 = (s2 == 2 ? b - 1 : b) * N1 + (l2 - a * NV);
-                aee[(size_t)a * NEP * NEP + e1 * NEP + e2] += v;
-              }
-            else if (s1 >= 2)
-              {
-                const int e1 = (s1 == 2 ? b - 1 : b) * N1 + (l1 - a * NV);
-                rg[(size_t)a * NEP * MP2 + e1 * MP2 + (s2 == 1 ? MP : 0) + i2] += v;
-              }
-          }
-        for (int idx = tid; idx < na * nb * RING; idx += 256)
-          {
-            const int cc = idx / RING, j = idx - cc * RING;
-            const int a = 2 * (cc / nb) + pa, b = 2 * (cc % nb) + pb, c = a * Cb + b;
-            int       l, i;
-            ring_node(a, b, j, l, i);
-            if (live(l, i))
-              xrow(l, i)[own_col(a, b)] += gvec[(size_t)c * RING + j];
-          }
-        __syncthreads();
-      }
-
-    }
-    stamp(5);
-    {
-    ND_LOCALS
-    // ------------------------------ level 1: edge sets of the strips ----------------------------
-    if ((ND_PHASES & 16) && NE > 0)
-      {
-        // V_EE = A_EE^{-1}, one wave per strip
-        for (int a = wave; a < Ca; a += 4)
-          {
-            double      *ae = aee + (size_t)a * NEP * NEP;
-            const int    gy = lane >> 3, gx = lane & 7;
-            double       t4[4][4];
-#pragma unroll
-            for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-              for (int tb = 0; tb < 4; ++tb)
-                t4[ta][tb] = ae[(4 * gy + ta) * NEP + 4 * gx + tb];
-            nd_gj_sweep<4>(t4, rowb, NE, lane, bad);
-#pragma unroll
-            for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-              for (int tb = 0; tb < 4; ++tb)
-                ae[(4 * gy + ta) * NEP + 4 * gx + tb] = -t4[ta][tb];
-          }
-        __syncthreads();
-        stamp(10);
-        // Y_H = V_EE A_EH, Y_G = V_EE G_E for all strips (independent)
-        {
-          constexpr int TH = MP2 / 16; // column tiles of the line part (MP2 = 16 T)
-          const int     tg = (ncg + 15) >> 4, per = 2 * (TH + tg);
-          for (int t = wave; t < Ca * per; t += 4)
-            {
-              const int     a = t / per, r = t - a * per, ti = r / (TH + tg), tj = r - ti * (TH + tg);
-              const double *ve = aee + (size_t)a * NEP * NEP, *re = rg + (size_t)a * NEP * MP2;
-              auto          fa = [&](int row, int k) -> double { return ve[row * NEP + k]; };
-              if (tj < TH)
-                {
-                  auto            fb = [&](int k, int col) -> double { return re[k * MP2 + col]; };
-                  const double4_t acc = nd_mfma_tile<NEP / 4>(fa, fb, ti, tj, lane);
-#pragma unroll
-                  for (int q = 0; q < 4; ++q)
-                    yh[(size_t)a * NEP * MP2 + (16 * ti + (lane >> 4) + 4 * q) * MP2 + 16 * tj + (lane & 15)] = acc[q];
-                }
-              else
-                {
-                  auto fb = [&](int k, int col) -> double {
-                    if (k >= NE || col >= nc)
-                      return 0.0;
-                    const int be = k / N1;
-                    return xrow(a * NV + (k - be * N1), be * NV + NV - 1)[col];
-                  };
-                  const double4_t acc = nd_mfma_tile<NEP / 4>(fa, fb, ti, tj - TH, lane);
-#pragma unroll
-                  for (int q = 0; q < 4; ++q)
-                    {
-                      const int col = 16 * (tj - TH) + (lane & 15);
-                      if (col < ncg)
-                        yg[(size_t)a * NEP * ncg + (16 * ti + (lane >> 4) + 4 * q) * ncg + col] = acc[q];
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        stamp(11);
-        // Schur complement onto the lines: strips one after the other (neighbouring strips share T_a)
+        constexpr int LDT = MP + 1, LDE = NEP + 1, TH = MP2 / 16, TI = (MP + 15) / 16;
+        const int     NCP = (ncg + 15) & ~15, RC = MP2 + NCP, TG = NCP / 16; // right-hand sides in whole column tiles
+        static_assert(MP2 % 16 == 0, "line pair in whole column tiles");
+        double *TT = smem, *EE = TT + 3 * MP * LDT, *RR = EE + NEP * LDE, *rowg = RR + NEP * RC;
+        int     sPrev = 0, sB = 1, sCur = 2;
+        const int gy = lane >> 3, gx = lane & 7, r16 = lane & 15, kq = lane >> 4;
         for (int a = 0; a < Ca; ++a)
           {
-            constexpr int TH = MP2 / 16;
-            const int     tg = (ncg + 15) >> 4;
-            const double *re = rg + (size_t)a * NEP * MP2, *ye = yh + (size_t)a * NEP * MP2, *ge = yg + (size_t)a * NEP * ncg;
-            auto          fa = [&](int row, int k) -> double { return re[k * MP2 + row]; };
-            for (int t = wave; t < TH * (TH + tg); t += 4)
+            const bool has_bot = a > 0, has_top = a < Ca - 1;
+            double    *Tp = TT + sPrev * MP * LDT, *Bb = TT + sB * MP * LDT, *Tc = TT + sCur * MP * LDT;
+            // (1) direct couplings (stencil entries between skeleton nodes), right-hand sides of the edges
+            for (int idx = tid; idx < NEP * NEP; idx += NT)
               {
-                const int ti = t / (TH + tg), tj = t - ti * (TH + tg);
-                if (tj < TH)
+                const int e1 = idx / NEP, e2 = idx - e1 * NEP;
+                double    v = 0.0;
+                if (e1 < NE && e2 < NE)
                   {
-                    // rows/columns: [0, MP) line a-1 (bottom), [MP, 2 MP) line a (top)
-                    if (16 * ti >= MP && 16 * tj + 15 < MP)
-                      continue; // top x bottom only: the transpose of bottom x top
-                    auto            fb = [&](int k, int col) -> double { return ye[k * MP2 + col]; };
-                    const double4_t acc = nd_mfma_tile<NEP / 4>(fa, fb, ti, tj, lane);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                      {
-                        const int  r1 = 16 * ti + (lane >> 4) + 4 * q, c1 = 16 * tj + (lane & 15);
-                        const bool t1 = r1 >= MP, t2 = c1 >= MP;
-                        const int  p1 = t1 ? r1 - MP : r1, p2 = t2 ? c1 - MP : c1;
-                        if (p1 >= m || p2 >= m)
-                          continue;
-                        if (!t1 && !t2 && a > 0)
-                          tm[(size_t)(a - 1) * MP * MP + p1 * MP + p2] -= acc[q];
-                        else if (t1 && t2 && a < Ca - 1)
-                          tm[(size_t)a * MP * MP + p1 * MP + p2] -= acc[q];
-                        else if (!t1 && t2 && a > 0 && a < Ca - 1)
-                          bm[(size_t)(a - 1) * MP * MP + p1 * MP + p2] -= acc[q];
-                      }
+                    const int b1 = e1 / N1, q1 = e1 - b1 * N1, b2 = e2 / N1, q2 = e2 - b2 * N1;
+                    if (b1 == b2 && q2 - q1 <= 1 && q1 - q2 <= 1)
+                      v = cpl(a * NV + q1, b1 * NV + NV - 1, q2 - q1, 0);
                   }
-                else
-                  {
-                    auto fb = [&](int k, int col) -> double { return col < ncg ? ge[k * ncg + col] : 0.0; };
-                    const double4_t acc = nd_mfma_tile<NEP / 4>(fa, fb, ti, tj - TH, lane);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                      {
-                        const int  r1 = 16 * ti + (lane >> 4) + 4 * q, col = 16 * (tj - TH) + (lane & 15);
-                        const bool t1 = r1 >= MP;
-                        const int  p1 = t1 ? r1 - MP : r1;
-                        if (p1 >= m || col >= nc || (t1 ? a >= Ca - 1 : a == 0))
-                          continue;
-                        xrow((t1 ? a : a - 1) * NV + NV - 1, p1)[col] -= acc[q];
-                      }
-                  }
+                EE[e1 * LDE + e2] = v;
               }
+            for (int idx = tid; idx < NEP * RC; idx += NT)
+              {
+                const int e = idx / RC, h = idx - e * RC;
+                double    v = 0.0;
+                if (e < NE)
+                  {
+                    const int be = e / N1, q = e - be * N1, ie = be * NV + NV - 1;
+                    if (h < MP2)
+                      {
+                        const int top = h >= MP, pos = top ? h - MP : h;
+                        if (pos < m && pos - ie <= 1 && ie - pos <= 1)
+                          {
+                            if (!top && q == 0 && has_bot)
+                              v = cpl(a * NV, ie, -1, pos - ie);
+                            if (top && q == N1 - 1 && has_top)
+                              v = cpl(a * NV + q, ie, 1, pos - ie);
+                          }
+                      }
+                    else if (h - MP2 < nc)
+                      v = xrow(a * NV + q, ie)[h - MP2];
+                  }
+                RR[idx] = v;
+              }
+            if (has_top)
+              for (int idx = tid; idx < MP * MP; idx += NT)
+                {
+                  const int i = idx / MP, j = idx - i * MP;
+                  double    v = 0.0;
+                  if (i < m && j < m && j - i <= 1 && i - j <= 1)
+                    v = cpl(a * NV + NV - 1, i, 0, j - i);
+                  Tc[i * LDT + j] = v;
+                  Bb[i * LDT + j] = 0.0;
+                }
             __syncthreads();
+            // (2) the cell matrices of the strip; cells b and b + 1 share ring nodes: even b, then odd b
+            for (int pb = 0; pb < 2; ++pb)
+              {
+                const int nbc = (Cb - pb + 1) / 2;
+                for (int idx = tid; idx < nbc * RING * RING; idx += NT)
+                  {
+                    const int cc = idx / (RING * RING), ent = idx - cc * RING * RING;
+                    const int b = 2 * cc + pb, c = a * Cb + b;
+                    const int j1 = ent / RING, j2 = ent - j1 * RING;
+                    int       l1, i1, l2, i2;
+                    ring_node(a, b, j1, l1, i1);
+                    ring_node(a, b, j2, l2, i2);
+                    if (!live(l1, i1) || !live(l2, i2))
+                      continue;
+                    const int    s1 = ring_side<NV>(j1), s2 = ring_side<NV>(j2);
+                    const double v = cmat[(size_t)c * RING * RING + ent];
+                    if (s1 < 2 && s2 < 2)
+                      {
+                        if (s1 == s2)
+                          (s1 == 0 ? Tp : Tc)[i1 * LDT + i2] += v;
+                        else if (s1 == 0)
+                          Bb[i1 * LDT + i2] += v;
+                      }
+                    else if (s1 >= 2 && s2 >= 2)
+                      {
+                        const int e1 = (s1 == 2 ? b - 1 : b) * N1 + (l1 - a * NV), e2 = (s2 == 2 ? b - 1 : b) * N1 + (l2 - a * NV);
+                        EE[e1 * LDE + e2] += v;
+                      }
+                    else if (s1 >= 2)
+                      {
+                        const int e1 = (s1 == 2 ? b - 1 : b) * N1 + (l1 - a * NV);
+                        RR[e1 * RC + (s2 == 1 ? MP : 0) + i2] += v;
+                      }
+                  }
+                __syncthreads();
+              }
+            // (3) edge set: V_EE, Y = V_EE R, Schur complement onto the two lines
+            if (NE > 0)
+              {
+                if (wave == 0)
+                  {
+                    double t4[4][4];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+#pragma unroll
+                      for (int q = 0; q < 4; ++q)
+                        t4[p][q] = EE[(4 * gy + p) * LDE + 4 * gx + q];
+                    nd_gj_sweep<4>(t4, rowg, NE, lane, bad);
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+#pragma unroll
+                      for (int q = 0; q < 4; ++q)
+                        EE[(4 * gy + p) * LDE + 4 * gx + q] = -t4[p][q];
+                  }
+                __syncthreads();
+                for (int jt = wave; jt < TH + TG; jt += NW)
+                  {
+                    const int col = 16 * jt + r16;
+                    double    bop[NEP / 4];
+#pragma unroll
+                    for (int kk = 0; kk < NEP / 4; ++kk)
+                      bop[kk] = RR[(4 * kk + kq) * RC + col];
+                    double4_t y[2];
+#pragma unroll
+                    for (int ti = 0; ti < 2; ++ti)
+                      {
+                        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int kk = 0; kk < NEP / 4; ++kk)
+                          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(EE[(16 * ti + r16) * LDE + 4 * kk + kq], bop[kk], acc, 0, 0, 0);
+                        y[ti] = acc;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                          {
+                            const int e = 16 * ti + kq + 4 * q;
+                            if (jt < TH)
+                              yh[(size_t)a * NEP * MP2 + e * MP2 + col] = acc[q];
+                            else if (col - MP2 < ncg)
+                              yg[(size_t)a * NEP * ncg + e * ncg + (col - MP2)] = acc[q];
+                          }
+                      }
+                    // U[:, jt] = R_H^T Y[:, jt]: the accumulator registers of Y are the B fragments
+                    for (int it = 0; it < TH; ++it)
+                      {
+                        if (jt < TH && 16 * it >= MP && 16 * jt + 15 < MP)
+                          continue; // top x bottom only: the transpose of bottom x top
+                        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int kk = 0; kk < NEP / 4; ++kk)
+                          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(RR[(4 * kk + kq) * RC + 16 * it + r16], y[kk >> 2][kk & 3], acc, 0, 0, 0);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                          {
+                            const int  r1 = 16 * it + kq + 4 * q;
+                            const bool t1 = r1 >= MP;
+                            const int  p1 = t1 ? r1 - MP : r1;
+                            if (p1 >= m)
+                              continue;
+                            if (jt < TH)
+                              {
+                                const bool t2 = col >= MP;
+                                const int  p2 = t2 ? col - MP : col;
+                                if (p2 >= m)
+                                  continue;
+                                if (!t1 && !t2 && has_bot)
+                                  Tp[p1 * LDT + p2] -= acc[q];
+                                else if (t1 && t2 && has_top)
+                                  Tc[p1 * LDT + p2] -= acc[q];
+                                else if (!t1 && t2 && has_bot && has_top)
+                                  Bb[p1 * LDT + p2] -= acc[q];
+                              }
+                            else if (col - MP2 < nc && (t1 ? has_top : has_bot))
+                              xrow((t1 ? a : a - 1) * NV + NV - 1, p1)[col - MP2] -= acc[q];
+                          }
+                      }
+                  }
+                __syncthreads();
+              }
+            // (4) the line below the strip is complete: eliminate it
+            if (has_bot)
+              {
+                const int la = (a - 1) * NV + NV - 1;
+                if (wave == 0)
+                  {
+                    double tt[T][T];
+#pragma unroll
+                    for (int p = 0; p < T; ++p)
+#pragma unroll
+                      for (int q = 0; q < T; ++q)
+                        tt[p][q] = Tp[(T * gy + p) * LDT + T * gx + q];
+                    nd_gj_sweep<T>(tt, rowg, m, lane, bad);
+#pragma unroll
+                    for (int p = 0; p < T; ++p)
+#pragma unroll
+                      for (int q = 0; q < T; ++q)
+                        Tp[(T * gy + p) * LDT + T * gx + q] = -tt[p][q];
+                  }
+                __syncthreads();
+                // column tiles: [0, TI) of W = V B (and P = B^T W into T of the line above), then the
+                // tiles of Z = V G (and G of the line above -= B^T Z)
+                const int tjn = (nc + 15) >> 4;
+                for (int jt = wave; jt < (has_top ? TI : 0) + tjn; jt += NW)
+                  {
+                    const bool isw = has_top && jt < TI;
+                    const int  jz = jt - (has_top ? TI : 0), col = 16 * (isw ? jt : jz) + r16;
+                    double     bop[KTM];
+#pragma unroll
+                    for (int kk = 0; kk < KTM; ++kk)
+                      {
+                        const int k = 4 * kk + kq;
+                        if (isw)
+                          bop[kk] = col < MP ? Bb[k * LDT + col] : 0.0;
+                        else
+                          bop[kk] = (k < m && col < nc) ? xrow(la, k)[col] : 0.0;
+                      }
+                    double4_t w[TI];
+#pragma unroll
+                    for (int ti = 0; ti < TI; ++ti)
+                      {
+                        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+                        const int row = 16 * ti + r16 < MP ? 16 * ti + r16 : MP - 1;
+#pragma unroll
+                        for (int kk = 0; kk < KTM; ++kk)
+                          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Tp[row * LDT + 4 * kk + kq], bop[kk], acc, 0, 0, 0);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                          {
+                            const int rr = 16 * ti + kq + 4 * q;
+                            if (rr >= m) // rows past the line are no unknowns: zero operand below
+                              acc[q] = 0.0;
+                            if (rr < MP)
+                              {
+                                if (isw && col < MP)
+                                  wm[(size_t)(a - 1) * MP * MP + rr * MP + col] = acc[q];
+                                else if (!isw && col < ncg)
+                                  zs[(size_t)(a - 1) * MP * ncg + rr * ncg + col] = acc[q];
+                              }
+                          }
+                        w[ti] = acc;
+                      }
+                    if (has_top)
+                      for (int it = 0; it < TI; ++it)
+                        {
+                          double4_t acc = {0.0, 0.0, 0.0, 0.0};
+                          const int rowi = 16 * it + r16;
+#pragma unroll
+                          for (int kk = 0; kk < 4 * TI; ++kk)
+                            {
+                              const int    k = 4 * kk + kq;
+                              const double av = (k < MP && rowi < MP) ? Bb[k * LDT + rowi] : 0.0;
+                              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, w[kk >> 2][kk & 3], acc, 0, 0, 0);
+                            }
+#pragma unroll
+                          for (int q = 0; q < 4; ++q)
+                            {
+                              const int rr = 16 * it + kq + 4 * q;
+                              if (rr >= m)
+                                continue;
+                              if (isw && col < m)
+                                Tc[rr * LDT + col] -= acc[q];
+                              else if (!isw && col < nc)
+                                xrow(la + NV, rr)[col] -= acc[q];
+                            }
+                        }
+                  }
+                __syncthreads();
+              }
+            const int keep = sPrev;
+            sPrev = sCur;
+            sCur  = sB;
+            sB    = keep;
           }
       }
-
     }
+
     stamp(6);
     {
     ND_LOCALS
-    // ------------------------------ level 2: the lines, block tridiagonal -----------------------
     if (ND_PHASES & 32)
     {
       constexpr int TI = (MP + 15) / 16;
       const int     tjn = (ncg + 15) >> 4;
-      for (int a = 0; a < nH; ++a)
-        {
-          double       *ta_ = tm + (size_t)a * MP * MP;
-          const int     la = a * NV + NV - 1;
-          if (wave == 0)
-            {
-              // V_a = (T_a - B_{a-1}^T W_{a-1})^{-1}
-              const int gy = lane >> 3, gx = lane & 7;
-              double    tt[T][T];
-#pragma unroll
-              for (int p = 0; p < T; ++p)
-#pragma unroll
-                for (int q = 0; q < T; ++q)
-                  {
-                    const int i = T * gy + p, j = T * gx + q;
-                    tt[p][q]    = ta_[i * MP + j] - (a > 0 ? pm[i * MP + j] : 0.0);
-                  }
-              nd_gj_sweep<T>(tt, rowb, m, lane, bad);
-#pragma unroll
-              for (int p = 0; p < T; ++p)
-#pragma unroll
-                for (int q = 0; q < T; ++q)
-                  ta_[(T * gy + p) * MP + T * gx + q] = -tt[p][q];
-            }
-          else if (a > 0)
-            {
-              // R_a = G_a - B_{a-1}^T Z_{a-1} (in the rows of X of line a)
-              const double *bp = bm + (size_t)(a - 1) * MP * MP, *zp = zs + (size_t)(a - 1) * MP * ncg;
-              auto          fa = [&](int row, int k) -> double { return bp[k * MP + row]; };
-              auto          fb = [&](int k, int col) -> double { return col < ncg ? zp[k * ncg + col] : 0.0; };
-              for (int t = wave - 1; t < TI * tjn; t += 3)
-                {
-                  const int       ti = t / tjn, tj = t - ti * tjn;
-                  const double4_t acc = nd_mfma_tile<KTM>(fa, fb, ti, tj, lane);
-#pragma unroll
-                  for (int q = 0; q < 4; ++q)
-                    {
-                      const int row = 16 * ti + (lane >> 4) + 4 * q, col = 16 * tj + (lane & 15);
-                      if (row < m && col < nc)
-                        xrow(la, row)[col] -= acc[q];
-                    }
-                }
-            }
-          __syncthreads();
-          {
-            // Z_a = V_a R_a; W_a = V_a B_a
-            const double *bp = bm + (size_t)a * MP * MP;
-            auto          fa = [&](int row, int k) -> double { return row < MP ? ta_[row * MP + k] : 0.0; };
-            const int     nz = TI * tjn, nw = a < nH - 1 ? TI * TI : 0;
-            for (int t = wave; t < nz + nw; t += 4)
-              {
-                if (t < nz)
-                  {
-                    const int ti = t / tjn, tj = t - ti * tjn;
-                    auto      fb = [&](int k, int col) -> double { return (k < m && col < nc) ? xrow(la, k)[col] : 0.0; };
-                    const double4_t acc = nd_mfma_tile<KTM>(fa, fb, ti, tj, lane);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                      {
-                        const int row = 16 * ti + (lane >> 4) + 4 * q, col = 16 * tj + (lane & 15);
-                        if (row < MP && col < ncg)
-                          zs[(size_t)a * MP * ncg + row * ncg + col] = acc[q];
-                      }
-                  }
-                else
-                  {
-                    const int ti = (t - nz) / TI, tj = (t - nz) - ti * TI;
-                    auto      fb = [&](int k, int col) -> double { return col < MP ? bp[k * MP + col] : 0.0; };
-                    const double4_t acc = nd_mfma_tile<KTM>(fa, fb, ti, tj, lane);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                      {
-                        const int row = 16 * ti + (lane >> 4) + 4 * q, col = 16 * tj + (lane & 15);
-                        if (row < MP && col < MP)
-                          wm[(size_t)a * MP * MP + row * MP + col] = acc[q];
-                      }
-                  }
-              }
-          }
-          __syncthreads();
-          if (a < nH - 1)
-            {
-              // P = B_a^T W_a (what line a+1 subtracts from T_{a+1})
-              const double *bp = bm + (size_t)a * MP * MP, *wp = wm + (size_t)a * MP * MP;
-              auto          fa = [&](int row, int k) -> double { return row < MP ? bp[k * MP + row] : 0.0; };
-              auto          fb = [&](int k, int col) -> double { return col < MP ? wp[k * MP + col] : 0.0; };
-              for (int t = wave; t < TI * TI; t += 4)
-                {
-                  const int       ti = t / TI, tj = t - ti * TI;
-                  const double4_t acc = nd_mfma_tile<KTM>(fa, fb, ti, tj, lane);
-#pragma unroll
-                  for (int q = 0; q < 4; ++q)
-                    {
-                      const int row = 16 * ti + (lane >> 4) + 4 * q, col = 16 * tj + (lane & 15);
-                      if (row < MP && col < MP)
-                        pm[row * MP + col] = acc[q];
-                    }
-                }
-              __syncthreads();
-            }
-        }
       stamp(12);
       // backward: X_a = Z_a - W_a X_{a+1}
       for (int a = nH - 1; a >= 0; --a)
@@ -995,7 +975,7 @@ namespace
           const double *wp = wm + (size_t)a * MP * MP, *zp = zs + (size_t)a * MP * ncg;
           auto          fa = [&](int row, int k) -> double { return row < MP ? wp[row * MP + k] : 0.0; };
           auto fb = [&](int k, int col) -> double { return (k < m && col < nc) ? xrow(la + NV, k)[col] : 0.0; };
-          for (int t = wave; t < TI * tjn; t += 4)
+          for (int t = wave; t < TI * tjn; t += NW)
             {
               const int ti = t / tjn, tj = t - ti * tjn;
               double4_t acc = {0.0, 0.0, 0.0, 0.0};
@@ -1021,7 +1001,7 @@ namespace
     if ((ND_PHASES & 64) && NE > 0)
       {
         const int tjn = (ncg + 15) >> 4;
-        for (int t = wave; t < Ca * 2 * tjn; t += 4)
+        for (int t = wave; t < Ca * 2 * tjn; t += NW)
           {
             const int     a = t / (2 * tjn), r = t - a * 2 * tjn, ti = r / tjn, tj = r - ti * tjn;
             const double *ye = yh + (size_t)a * NEP * MP2, *ge = yg + (size_t)a * NEP * ncg;
@@ -1061,10 +1041,10 @@ namespace
         nd_prefetch_1k(facg + (size_t)wave * lay.cblk + 4 * ND_BST, lane_, pf);
       }
     if (ND_PHASES & 128)
-    for (int c = wave; c < ncell; c += 4)
+    for (int c = wave; c < ncell; c += NW)
       {
         const int     a = c / Cb, b = c - a * Cb, l0 = a * NV, i0 = b * NV;
-        const double *fac = facg + (size_t)c * lay.cblk, *fac_next = facg + (size_t)(c + 4 < ncell ? c + 4 : c) * lay.cblk;
+        const double *fac = facg + (size_t)c * lay.cblk, *fac_next = facg + (size_t)(c + NW < ncell ? c + NW : c) * lay.cblk;
         int           lane = lane_;
         asm volatile("" : "+v"(lane));
         const int pl = lane < PST ? lane : PST - 1;
@@ -1159,11 +1139,7 @@ namespace
       atomicOr(A.status, 1);
     stamp(9);
 
-    if ((ND_PHASES & 256) && A.fuse_select)
-      {
-        __syncthreads(); // X of all nodes is written; LDS is free
-        select_patch<1>(A, A.nb_buf, A.nf_max, blockIdx.x, smem);
-      }
+    // (the selection stage runs as its own launch, k_select: it is written for 256-thread workgroups)
     }
   }
 
@@ -1180,10 +1156,10 @@ static hipError_t launch_nd(const SlodKernelArgs &a, int n_patches, size_t lds, 
   if (a.debug)
     {
       int nb = 0;
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, lds);
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * ND_WAVES, lds);
       fprintf(stderr, "[slod] k_solve_nd<%d,%d>: %d patches, lds %zu B, occupancy %d blocks/CU\n", NV, T, n_patches, lds, nb);
     }
-  hipLaunchKernelGGL((k_solve_nd<NV, T>), dim3(n_patches), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((k_solve_nd<NV, T>), dim3(n_patches), dim3(64 * ND_WAVES), lds, st, a);
   return hipGetLastError();
 }
 

@@ -36,12 +36,12 @@ lib.slod_debug_read_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_size_t
 assert lib.slod_debug_read_ms(plan.p, buf.ctypes.data_as(C.POINTER(C.c_double)), buf.size) == 0
 raw = buf.reshape(len(ids), ncm * ncm) / 100.0  # microseconds
 st = raw[:, 32:46]
-names = ["assemble", "factor", "condense", "init", "scatter", "E:gj", "E:Y", "E:schur", "H:fwd", "H:bwd", "back E",
-         "back cells"]
-# stamp order: 0 start,1 after assemble,2 after factor,3 after init,4 condense,5 scatter,10 E gj,11 E Y,6 E schur,12 H fwd,7 H bwd,8 back E,9 back cells
-order = [0, 1, 2, 3, 4, 5, 10, 11, 6, 12, 7, 8, 9]
+names = ["assemble", "factor", "condense", "rhs", "skeleton", "-", "H:bwd", "back E", "back cells"]
+# stamps: 0 start, 1 after assemble, 2 after factor, 3 after condense, 4 after rhs, 6 after the skeleton sweep,
+# 12 before the backward line sweep, 7 after it, 8 after the edge back substitution, 9 end
+order = [0, 1, 2, 3, 4, 6, 12, 7, 8, 9]
 t0 = st[:, 0].min()
-sel_end = raw[:, 11]
+sel_end = st[:, 9]  # (selection stage: its own launch)
 shapes = {}
 for k, pid in enumerate(ids):
     info = g.patch_layout(int(pid))
@@ -49,9 +49,9 @@ for k, pid in enumerate(ids):
 print("launch span %.1f us (kernel_ms %s)" % (max(sel_end.max(), st[:, 9].max()) - t0, plan.kernel_ms()))
 for key in sorted(shapes):
     idx = shapes[key]
-    d = np.array([[st[k, order[j + 1]] - st[k, order[j]] for j in range(12)] for k in idx])
+    d = np.array([[st[k, order[j + 1]] - st[k, order[j]] for j in range(len(order) - 1)] for k in idx])
     tot = st[idx, 9] - st[idx, 0]
     sel = sel_end[idx] - st[idx, 9]
     print("shape %dx%d n=%4d solve %.1f (max %.1f) select %.1f (max %.1f) | " % (key[0], key[1], len(idx), tot.mean(), tot.max(),
                                                                            sel.mean(), sel.max())
-          + "  ".join("%s %.1f" % (names[j], d[:, j].mean()) for j in range(12)))
+          + "  ".join("%s %.1f" % (names[j], d[:, j].mean()) for j in range(len(order) - 1)))
