@@ -261,7 +261,10 @@ int slod_gather_piece(uint64_t patches_per_rank, uint32_t n_pieces, uint32_t pie
  * into this rank's slab  d_*_all + rank * patches_per_rank * stride;  as soon as a piece is
  * done, comm_stream exchanges that piece of EVERY rank (grouped in-place broadcasts, one per
  * root) while the next piece is computed.  On return (asynchronous) compute_stream is ordered
- * after the exchange.  Every rank must call it with the same patches_per_rank and n_pieces. */
+ * after the exchange.  Every rank must call it with the same patches_per_rank and n_pieces.
+ * Error path: a rank that fails before the grouped broadcasts are issued returns non-zero WITHOUT
+ * entering the collective; its peers then wait inside RCCL.  Treat a non-zero return on any rank as
+ * fatal for the communicator (destroy it, or abort the job): there is no recovery inside the call. */
 int slod_plan_execute_allgather(slod_plan *p, slod_comm *c, double *d_basis_all, double *d_premult_all,
                                 size_t patches_per_rank, int n_pieces, void *compute_stream,
                                 void *comm_stream);
