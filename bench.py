@@ -149,7 +149,8 @@ def lod_system_leg(slod, torch, dev, basis, premult, stride):
         "lod_solve": {"iters": it_lod, "ms": t_sol, "rel_residual": res_lod, "preconditioner": "Jacobi",
                       "GBps": gbps(it_lod * 8.0 * NP * cap * (s * s + 0.5), t_sol)},
         "reconstruct_ms": t_rec, "reconstruct_GBps": gbps(slab_bytes + 8.0 * nfine, t_rec),
-        "fem_solve": {"iters": it_fem, "ms": t_fem, "rel_residual": res_fem, "preconditioner": "Jacobi",
+        "fem_solve": {"iters": it_fem, "ms": t_fem, "rel_residual": res_fem,
+                      "preconditioner": os.environ.get("SLOD_FEM_PRECOND", "multigrid V(2,2), Galerkin, damped Jacobi" if s == 1 else "Jacobi"),
                       "unknowns": nfine, "GBps": gbps(it_fem * 8.0 * nfine * (9 * s * s + 6), t_fem)},
         "rel_l2_lod_vs_fem": err,
         "bytes_model": "lod_matrix: (phi,psi) slab once + the block rows written; lod_rhs/reconstruct: phi slab + fine vector; "

@@ -400,6 +400,217 @@ namespace
       }
   }
 
+  // ---- geometric multigrid V-cycle on the 9-point block stencil planes: the preconditioner of the
+  // fine FEM reference solve (the reference uses CG + AMG, LOD.cc:1070-1075).  Levels halve the grid
+  // while the number of elements per side is even; bilinear interpolation P, restriction P^T, Galerkin
+  // coarse operators P^T A P (again 9-point stencils), damped-Jacobi smoothing with the same number
+  // of sweeps before and after the coarse correction (a symmetric positive definite preconditioner).
+  // Dirichlet nodes (all four sides) carry 0 on every level and are no unknowns.
+  __device__ __forceinline__ double mg_w(int f, int c) // 1-D bilinear weight of coarse node c at fine node f
+  {
+    const int dlt = f - 2 * c;
+    return dlt == 0 ? 1.0 : ((dlt == 1 || dlt == -1) ? 0.5 : 0.0);
+  }
+  // coarse planes from fine planes: one thread per coarse node
+  __global__ void k_mg_galerkin(int Nf, int s, const double *stf, double *stc)
+  {
+    const int Nc = Nf / 2, npc = Nc + 1, nnc = npc * npc, npf = Nf + 1, nnf = npf * npf;
+    const int node = blockIdx.x * 256 + threadIdx.x;
+    if (node >= nnc)
+      return;
+    const int X = node % npc, Y = node / npc;
+    double    acc[9][2][2];
+    for (int q = 0; q < 9; ++q)
+      for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b)
+          acc[q][a][b] = 0.0;
+    const bool bnd = X == 0 || Y == 0 || X == Nc || Y == Nc;
+    if (!bnd)
+      for (int ay = -1; ay <= 1; ++ay)
+        for (int ax = -1; ax <= 1; ++ax)
+          {
+            const int ix = 2 * X + ax, iy = 2 * Y + ay; // fine node in the support of the coarse hat (interior)
+            if (ix <= 0 || iy <= 0 || ix >= Nf || iy >= Nf)
+              continue;
+            const double wi = mg_w(ix, X) * mg_w(iy, Y);
+            const int    fn = ix + iy * npf;
+            for (int dy = -1; dy <= 1; ++dy)
+              for (int dx = -1; dx <= 1; ++dx)
+                {
+                  const int jx = ix + dx, jy = iy + dy;
+                  if (jx <= 0 || jy <= 0 || jx >= Nf || jy >= Nf)
+                    continue; // constrained fine neighbour
+                  const int dir = (dy + 1) * 3 + dx + 1;
+                  for (int DY = -1; DY <= 1; ++DY)
+                    for (int DX = -1; DX <= 1; ++DX)
+                      {
+                        const double wj = mg_w(jx, X + DX) * mg_w(jy, Y + DY);
+                        if (wj == 0.0)
+                          continue;
+                        const int q = (DY + 1) * 3 + DX + 1;
+                        for (int a = 0; a < s; ++a)
+                          for (int b = 0; b < s; ++b)
+                            acc[q][a][b] = fma(wi * wj, stf[(size_t)((dir * s + a) * s + b) * nnf + fn], acc[q][a][b]);
+                      }
+                }
+          }
+    for (int q = 0; q < 9; ++q)
+      for (int a = 0; a < s; ++a)
+        for (int b = 0; b < s; ++b)
+          stc[(size_t)((q * s + a) * s + b) * nnc + node] = acc[q][a][b];
+  }
+  // (A x)(node, a) on the interior, constrained neighbours skipped
+  __device__ __forceinline__ double mg_apply(int N, int s, const double *st, const double *x, int ix, int iy, int a)
+  {
+    const int np = N + 1, nn = np * np, node = ix + iy * np;
+    double    acc = 0.0;
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx)
+        {
+          const int jx = ix + dx, jy = iy + dy;
+          if (jx == 0 || jy == 0 || jx == N || jy == N)
+            continue;
+          const int dir = (dy + 1) * 3 + dx + 1, nb = jx + jy * np;
+          for (int b = 0; b < s; ++b)
+            acc = fma(st[(size_t)((dir * s + a) * s + b) * nn + node], x[(size_t)nb * s + b], acc);
+        }
+    return acc;
+  }
+  // xo = xi + omega D^-1 (b - A xi)   (zero_in: xi = 0)
+  __global__ void k_mg_smooth(int N, int s, const double *st, const double *b, const double *xi, double *xo, double omega,
+                              int zero_in)
+  {
+    const int np = N + 1, nn = np * np, node = blockIdx.x * 256 + threadIdx.x;
+    if (node >= nn)
+      return;
+    const int  ix = node % np, iy = node / np;
+    const bool bnd = ix == 0 || iy == 0 || ix == N || iy == N;
+    double     r[2] = {0.0, 0.0}, v[2] = {0.0, 0.0};
+    if (!bnd)
+      {
+        for (int a = 0; a < s; ++a)
+          r[a] = b[(size_t)node * s + a] - (zero_in ? 0.0 : mg_apply(N, s, st, xi, ix, iy, a));
+        // block Jacobi: the s x s diagonal block of the node (vector problems: point Jacobi stalls where lambda >> mu)
+        const double d00 = st[(size_t)((4 * s + 0) * s + 0) * nn + node];
+        if (s == 1)
+          v[0] = r[0] / d00;
+        else
+          {
+            const double d01 = st[(size_t)((4 * s + 0) * s + 1) * nn + node], d10 = st[(size_t)((4 * s + 1) * s + 0) * nn + node],
+                         d11 = st[(size_t)((4 * s + 1) * s + 1) * nn + node];
+            const double det = d00 * d11 - d01 * d10;
+            v[0]             = (d11 * r[0] - d01 * r[1]) / det;
+            v[1]             = (d00 * r[1] - d10 * r[0]) / det;
+          }
+      }
+    for (int a = 0; a < s; ++a)
+      {
+        const size_t i = (size_t)node * s + a;
+        xo[i]          = bnd ? 0.0 : (zero_in ? 0.0 : xi[i]) + omega * v[a];
+      }
+  }
+  // bc = P^T (b - A x): one thread per coarse node gathers its 3 x 3 fine residuals
+  __global__ void k_mg_restrict(int Nf, int s, const double *st, const double *b, const double *x, double *bc)
+  {
+    const int Nc = Nf / 2, npc = Nc + 1, nnc = npc * npc, npf = Nf + 1;
+    const int node = blockIdx.x * 256 + threadIdx.x;
+    if (node >= nnc)
+      return;
+    const int  X = node % npc, Y = node / npc;
+    const bool bnd = X == 0 || Y == 0 || X == Nc || Y == Nc;
+    for (int a = 0; a < s; ++a)
+      {
+        double acc = 0.0;
+        if (!bnd)
+          for (int ay = -1; ay <= 1; ++ay)
+            for (int ax = -1; ax <= 1; ++ax)
+              {
+                const int ix = 2 * X + ax, iy = 2 * Y + ay;
+                if (ix <= 0 || iy <= 0 || ix >= Nf || iy >= Nf)
+                  continue;
+                const double r = b[(size_t)(ix + iy * npf) * s + a] - mg_apply(Nf, s, st, x, ix, iy, a);
+                acc            = fma(mg_w(ix, X) * mg_w(iy, Y), r, acc);
+              }
+        bc[(size_t)node * s + a] = acc;
+      }
+  }
+  // x += P xc
+  __global__ void k_mg_prolong_add(int Nf, int s, const double *xc, double *x)
+  {
+    const int Nc = Nf / 2, npc = Nc + 1, npf = Nf + 1, nnf = npf * npf;
+    const int node = blockIdx.x * 256 + threadIdx.x;
+    if (node >= nnf)
+      return;
+    const int ix = node % npf, iy = node / npf;
+    if (ix == 0 || iy == 0 || ix == Nf || iy == Nf)
+      return;
+    for (int a = 0; a < s; ++a)
+      {
+        double acc = 0.0;
+        for (int Y = iy / 2; Y <= (iy + 1) / 2; ++Y)
+          for (int X = ix / 2; X <= (ix + 1) / 2; ++X)
+            acc = fma(mg_w(ix, X) * mg_w(iy, Y), xc[(size_t)(X + Y * npc) * s + a], acc);
+        x[(size_t)node * s + a] += acc;
+      }
+  }
+  // CG pieces around a general preconditioner: x += alpha p, r -= alpha Ap, rr; then rz_new = r.z
+  __global__ void k_pcg_update_xr(int nrow, const double *pv, const double *Ap, double *x, double *r, CgScalars *sc)
+  {
+    const int    i = blockIdx.x * 256 + threadIdx.x;
+    const double alpha = sc->pAp != 0.0 ? sc->rz / sc->pAp : 0.0;
+    double       b = 0.0;
+    if (i < nrow)
+      {
+        x[i] = fma(alpha, pv[i], x[i]);
+        r[i] = fma(-alpha, Ap[i], r[i]);
+        b    = r[i] * r[i];
+      }
+    for (int off = 32; off > 0; off >>= 1)
+      b += __shfl_xor(b, off, 64);
+    if ((threadIdx.x & 63) == 0)
+      atomicAdd(&sc->rr, b);
+  }
+  __global__ void k_pcg_dot_rz(int nrow, const double *r, const double *z, CgScalars *sc, int first)
+  {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double    a = i < nrow ? r[i] * z[i] : 0.0;
+    for (int off = 32; off > 0; off >>= 1)
+      a += __shfl_xor(a, off, 64);
+    if ((threadIdx.x & 63) == 0)
+      atomicAdd(first ? &sc->rz : &sc->rz_new, a);
+  }
+  __global__ void k_pcg_init(int NE, int s, const double *rhs, double *x, double *r, CgScalars *sc)
+  {
+    const int np = NE + 1, nn = np * np, node = blockIdx.x * 256 + threadIdx.x;
+    double    b = 0.0;
+    if (node < nn)
+      {
+        const int  ix = node % np, iy = node / np;
+        const bool bnd = ix == 0 || iy == 0 || ix == NE || iy == NE;
+        for (int c = 0; c < s; ++c)
+          {
+            const size_t i = (size_t)node * s + c;
+            const double f = bnd ? 0.0 : rhs[i];
+            x[i]           = 0.0;
+            r[i]           = f;
+            b += f * f;
+          }
+      }
+    for (int off = 32; off > 0; off >>= 1)
+      b += __shfl_xor(b, off, 64);
+    if ((threadIdx.x & 63) == 0)
+      {
+        atomicAdd(&sc->rhs2, b);
+        atomicAdd(&sc->rr, b);
+      }
+  }
+  __global__ void k_copy(int n, const double *src, double *dst)
+  {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n)
+      dst[i] = src[i];
+  }
+
   // ---- inputs produced on the device ----
   // ---- the plan's patch descriptors, built on the device (create_patches + create_mesh_for_patch +
   //      the index-set sizes, LOD.cc:122-244,770-858; one thread per patch of the plan).  Also: the plan's
@@ -903,6 +1114,135 @@ int slod_fem_solve(slod_handle *h, uint32_t problem, const double *d_fine_rhs, d
       if (e == hipSuccess)
         e = slod_launch_assemble(s, a, 1, st);
     }
+  const char *pc_env = std::getenv("SLOD_FEM_PRECOND");
+  // (scalar problems: with two independent high-contrast Lame fields the point/block-Jacobi smoothed
+  // V-cycle is a worse preconditioner than plain Jacobi -- 4500 against 1376 iterations on the 65^2
+  // grid -- so vector problems keep Jacobi unless SLOD_FEM_PRECOND=mg asks for it)
+  const bool  want_mg = pc_env ? !strcmp(pc_env, "mg") : s == 1;
+  const bool  use_mg = want_mg && NE >= 4 && NE % 2 == 0;
+  // multigrid hierarchy (level 0 = the fine grid): planes, right-hand side, two iterates per level
+  struct MgLevel
+  {
+    int     N;
+    double *st, *b, *x, *y;
+  };
+  std::vector<MgLevel> lev;
+  double              *mg_mem = nullptr;
+  if (e == hipSuccess && use_mg)
+    {
+      size_t need = 0;
+      for (int N = NE; ; N /= 2)
+        {
+          const size_t nnl = (size_t)(N + 1) * (N + 1);
+          need += (N == NE ? 0 : (size_t)9 * s * s * nnl) + 3 * nnl * s;
+          lev.push_back({N, nullptr, nullptr, nullptr, nullptr});
+          if (N % 2 || N / 2 < 2)
+            break;
+        }
+      e = hipMalloc((void **)&mg_mem, need * sizeof(double));
+      double *q = mg_mem;
+      for (size_t l = 0; l < lev.size() && e == hipSuccess; ++l)
+        {
+          const size_t nnl = (size_t)(lev[l].N + 1) * (lev[l].N + 1);
+          lev[l].st = l == 0 ? planes : q;
+          q += l == 0 ? 0 : (size_t)9 * s * s * nnl;
+          lev[l].b = q;
+          lev[l].x = q + nnl * s;
+          lev[l].y = q + 2 * nnl * s;
+          q += 3 * nnl * s;
+          if (l > 0)
+            hipLaunchKernelGGL(k_mg_galerkin, dim3((unsigned)((nnl + 255) / 256)), dim3(256), 0, st, lev[l - 1].N, s, lev[l - 1].st,
+                               lev[l].st);
+        }
+      if (e == hipSuccess)
+        e = hipGetLastError();
+    }
+  // z = V-cycle(r): V(2,2), damped Jacobi (omega 0.8); the coarsest level by a fixed, even number of sweeps
+  auto vcycle = [&](const double *rin, double *zout) {
+    const double omega = 0.8;
+    const int    nu = 2;
+    for (size_t l = 0; l < lev.size(); ++l)
+      {
+        const MgLevel &L = lev[l];
+        const int      nnl = (L.N + 1) * (L.N + 1), nb = (nnl + 255) / 256;
+        const double  *bl = l == 0 ? rin : L.b;
+        const bool     last = l + 1 == lev.size();
+        const int      sweeps = last ? (L.N <= 2 ? 2 : 40) : nu;
+        double        *xi = L.x, *xo = L.y;
+        for (int k = 0; k < sweeps; ++k)
+          {
+            hipLaunchKernelGGL(k_mg_smooth, dim3(nb), dim3(256), 0, st, L.N, s, L.st, bl, xi, xo, L.N <= 2 ? 1.0 : omega, k == 0 ? 1 : 0);
+            std::swap(xi, xo);
+          }
+        // sweeps is even: the current iterate is back in L.x
+        if (!last)
+          {
+            const int nnc = (L.N / 2 + 1) * (L.N / 2 + 1);
+            hipLaunchKernelGGL(k_mg_restrict, dim3((nnc + 255) / 256), dim3(256), 0, st, L.N, s, L.st, bl, L.x, lev[l + 1].b);
+          }
+      }
+    for (size_t l = lev.size() - 1; l-- > 0;)
+      {
+        const MgLevel &L = lev[l];
+        const int      nnl = (L.N + 1) * (L.N + 1), nb = (nnl + 255) / 256;
+        const double  *bl = l == 0 ? rin : L.b;
+        hipLaunchKernelGGL(k_mg_prolong_add, dim3(nb), dim3(256), 0, st, L.N, s, lev[l + 1].x, L.x);
+        double *xi = L.x, *xo = L.y;
+        for (int k = 0; k < nu; ++k)
+          {
+            hipLaunchKernelGGL(k_mg_smooth, dim3(nb), dim3(256), 0, st, L.N, s, L.st, bl, xi, xo, omega, 0);
+            std::swap(xi, xo);
+          }
+      }
+    hipLaunchKernelGGL(k_copy, dim3((unsigned)((nrow + 255) / 256)), dim3(256), 0, st, (int)nrow, lev[0].x, zout);
+  };
+  if (e == hipSuccess && use_mg)
+    {
+      double   *r = work, *z = work + nrow, *pv = work + 2 * nrow, *Ap = work + 3 * nrow;
+      const int nb1 = (int)((nrow + 255) / 256);
+      hipLaunchKernelGGL(k_pcg_init, dim3(nblk), dim3(256), 0, st, NE, s, d_fine_rhs, d_fine_u, r, sc);
+      vcycle(r, z);
+      hipLaunchKernelGGL(k_pcg_dot_rz, dim3(nb1), dim3(256), 0, st, (int)nrow, r, z, sc, 1);
+      hipLaunchKernelGGL(k_copy, dim3(nb1), dim3(256), 0, st, (int)nrow, z, pv);
+      e = hipMemcpyAsync(&hs, sc, sizeof(hs), hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess)
+        e = hipStreamSynchronize(st);
+      const double rhs2 = hs.rhs2;
+      double       rr   = hs.rr;
+      if (e == hipSuccess)
+        {
+          hs.rr = 0.0;
+          hs.pAp = 0.0;
+          hs.rz_new = 0.0;
+          e = hipMemcpyAsync(sc, &hs, sizeof(hs), hipMemcpyHostToDevice, st);
+        }
+      while (e == hipSuccess && it < max_iterations && rhs2 > 0.0 && rr > rel_tol * rel_tol * rhs2)
+        {
+          const int burst = std::min(4, max_iterations - it); // iterations per convergence check
+          for (int b = 0; b < burst; ++b)
+            {
+              hipLaunchKernelGGL(k_fem_spmv_dot, dim3(nblk), dim3(256), 0, st, NE, s, planes, pv, Ap, sc);
+              hipLaunchKernelGGL(k_pcg_update_xr, dim3(nb1), dim3(256), 0, st, (int)nrow, pv, Ap, d_fine_u, r, sc);
+              vcycle(r, z);
+              hipLaunchKernelGGL(k_pcg_dot_rz, dim3(nb1), dim3(256), 0, st, (int)nrow, r, z, sc, 0);
+              hipLaunchKernelGGL(k_cg_update_p, dim3(nb1), dim3(256), 0, st, (int)nrow, z, pv, sc);
+              if (b + 1 < burst)
+                hipLaunchKernelGGL(k_cg_rotate, dim3(1), dim3(1), 0, st, sc);
+            }
+          it += burst;
+          e = hipMemcpyAsync(&hs, sc, sizeof(hs), hipMemcpyDeviceToHost, st);
+          if (e == hipSuccess)
+            e = hipStreamSynchronize(st);
+          rr = hs.rr;
+          if (e == hipSuccess)
+            hipLaunchKernelGGL(k_cg_rotate, dim3(1), dim3(1), 0, st, sc);
+        }
+      if (e == hipSuccess)
+        e = hipStreamSynchronize(st);
+      if (rel_residual)
+        *rel_residual = rhs2 > 0.0 ? std::sqrt(rr / rhs2) : 0.0;
+    }
+  else
   if (e == hipSuccess)
     {
       double *r = work, *z = work + nrow, *pv = work + 2 * nrow, *Ap = work + 3 * nrow, *dinv = work + 4 * nrow;
@@ -945,6 +1285,8 @@ int slod_fem_solve(slod_handle *h, uint32_t problem, const double *d_fine_rhs, d
       if (rel_residual)
         *rel_residual = rhs2 > 0.0 ? std::sqrt(rr / rhs2) : 0.0;
     }
+  if (mg_mem)
+    (void)hipFree(mg_mem);
   if (planes)
     (void)hipFree(planes);
   if (work)

@@ -350,7 +350,7 @@ def test_fem_rhs_matches_example_golden(so):
                                      (dict(nref=3, n_sub=4, oversampling=1, spacedim=1), "D1e4"),
                                      (dict(nref=2, n_sub=4, oversampling=1, spacedim=2), "D100")])
 def test_fem_solve_matches_sparse_direct(so, kw, dist):
-    """Matrix-free Jacobi-CG on the device stencil planes against scipy's sparse direct solve of the
+    """Matrix-free (multigrid-preconditioned) CG on the device stencil planes against scipy's sparse direct solve of the
     same fine problem (independent assembly from oracle/slod_numpy.element_matrix)."""
     import scipy.sparse.linalg as spl
     torch, dev = _torch()
@@ -371,6 +371,33 @@ def test_fem_solve_matches_sparse_direct(so, kw, dist):
     mask = np.ones(uh.size, bool)
     mask[idx] = False
     assert np.all(uh[mask] == 0.0)
+
+
+@pytest.mark.parametrize("spacedim", [1, 2])
+def test_fem_multigrid_preconditioner(so, spacedim, monkeypatch):
+    """The fine FEM reference solve is CG with a geometric multigrid V-cycle (Galerkin coarse operators
+    on the stencil planes; the reference uses CG + AMG, LOD.cc:1070-1075).  Same solution as the
+    Jacobi-preconditioned CG (SLOD_FEM_PRECOND=jacobi), several times fewer iterations at contrast 1e4."""
+    torch, dev = _torch()
+    kw = dict(nref=4, n_sub=4, oversampling=1, spacedim=spacedim)
+    cfg, g = _mk(so, stabilize=1, **kw)
+    fields = make_fields(so, cfg, "D1e4")
+    _upload(g, fields)
+    NEp = g.NE + 1
+    rhs = torch.zeros(NEp * NEp * spacedim, dtype=torch.float64, device=dev)
+    g.fem_rhs(None, rhs.data_ptr())
+    u_mg = torch.zeros_like(rhs)
+    it_mg, res_mg = g.fem_solve(rhs.data_ptr(), u_mg.data_ptr(), 1e-12, 20000)
+    monkeypatch.setenv("SLOD_FEM_PRECOND", "jacobi")
+    u_j = torch.zeros_like(rhs)
+    it_j, res_j = g.fem_solve(rhs.data_ptr(), u_j.data_ptr(), 1e-12, 20000)
+    assert res_mg <= 1e-12 and res_j <= 1e-12
+    assert float((u_mg - u_j).abs().max()) <= 1e-8 * float(u_j.abs().max())
+    if spacedim == 1:
+        assert 0 < it_mg < it_j / 3, (it_mg, it_j)
+    else:   # vector problems keep Jacobi by default (the V-cycle is opt-in there: SLOD_FEM_PRECOND=mg)
+        assert it_mg == it_j
+    print("fine FEM solve, %d components, 65^2 nodes, contrast 1e4: multigrid-CG %d iterations, Jacobi-CG %d" % (spacedim, it_mg, it_j))
 
 
 def test_lod_solution_converges_to_fem_with_oversampling(so):
