@@ -51,6 +51,16 @@ struct slod_plan
   int                        depth = 1; // event slots (slod_plan_profile)
   size_t                     n_exec = 0;
   bool                       ran = false;
+  // slod_plan_set_overlap(2): a second workspace and two internal streams, consecutive executes alternate
+  struct AltWs
+  {
+    double  *ws_st = nullptr, *ws_v = nullptr, *ws_x_alloc = nullptr, *ws_x = nullptr, *ws_z = nullptr, *ws_m = nullptr;
+    int32_t *d_status = nullptr;
+  } alt;
+  int         overlap = 1;
+  hipStream_t istream[2] = {nullptr, nullptr};
+  hipEvent_t  fork_ev = nullptr, done_ev[2] = {nullptr, nullptr};
+  bool        inflight[2] = {false, false};
   bool                       uniform_stride = true; // NULL offsets: patch k at k * stride
   std::vector<char>          prob_used;             // [n_problems] coefficient realisations the plan reads
 };
@@ -173,7 +183,7 @@ int slod_ensure_device(slod_handle *h)
 
 namespace
 {
-  SlodKernelArgs make_args(const slod_plan *p, size_t first, double *d_basis, double *d_premult, bool balanced)
+  SlodKernelArgs make_args(const slod_plan *p, size_t first, double *d_basis, double *d_premult, bool balanced, int slot = 0)
   {
     const slod_handle *h = p->h;
     SlodKernelArgs     a;
@@ -213,6 +223,15 @@ namespace
     a.premult   = d_premult;
     a.status    = p->d_status;
     a.pdiag     = p->d_pdiag;
+    if (slot == 1)
+      {
+        a.st     = p->alt.ws_st;
+        a.vinv   = p->alt.ws_v;
+        a.xs     = p->alt.ws_x;
+        a.zs     = p->alt.ws_z ? p->alt.ws_z : p->alt.ws_x;
+        a.ms     = p->alt.ws_m;
+        a.status = p->alt.d_status;
+      }
     return a;
   }
 } // namespace
@@ -222,10 +241,10 @@ namespace
   // the launches of the patches [first, first + cnt) of a plan (cnt <= chunk: one workspace slot per
   // workgroup); ev (optional): four events around the three stages
   hipError_t launch_range(slod_plan *p, size_t first, int cnt, double *d_basis, double *d_premult, hipStream_t st,
-                          hipEvent_t *ev, bool balanced)
+                          hipEvent_t *ev, bool balanced, int slot = 0)
   {
     const int      s = p->h->cfg.spacedim;
-    SlodKernelArgs a = make_args(p, first, d_basis, d_premult, balanced);
+    SlodKernelArgs a = make_args(p, first, d_basis, d_premult, balanced, slot);
     hipError_t     e = ev ? hipEventRecord(ev[0], st) : hipSuccess;
     if (e == hipSuccess && !p->choice.fuse_assemble)
       e = slod_launch_assemble(s, a, cnt, st);
@@ -654,6 +673,19 @@ void slod_plan_destroy(slod_plan *p)
     (void)hipFree(p->ws_m);
   if (p->d_status)
     (void)hipFree(p->d_status);
+  for (void *q : {(void *)p->alt.ws_st, (void *)p->alt.ws_v, (void *)p->alt.ws_x_alloc, (void *)p->alt.ws_z, (void *)p->alt.ws_m,
+                  (void *)p->alt.d_status})
+    if (q)
+      (void)hipFree(q);
+  for (int k = 0; k < 2; ++k)
+    {
+      if (p->istream[k])
+        (void)hipStreamDestroy(p->istream[k]);
+      if (p->done_ev[k])
+        (void)hipEventDestroy(p->done_ev[k]);
+    }
+  if (p->fork_ev)
+    (void)hipEventDestroy(p->fork_ev);
   if (p->d_pdiag)
     (void)hipFree(p->d_pdiag);
   delete p;
@@ -678,17 +710,100 @@ int slod_plan_execute(slod_plan *p, double *d_basis, double *d_premult, void *hi
   (void)hipSetDevice(h->cfg.device);
   hipStream_t st = hip_stream ? (hipStream_t)hip_stream : h->stream;
   const int   s  = h->cfg.spacedim;
-  hipError_t  e  = hipMemsetAsync(p->d_status, 0, sizeof(int32_t), st);
-  size_t      ci = 0;
+  hipError_t  e  = hipSuccess;
+  int         slot = 0;
+  if (p->overlap == 2)
+    {
+      // consecutive executes alternate between two workspaces and two internal streams: the work is
+      // ordered after everything submitted to the caller's stream so far, the caller's stream is NOT
+      // ordered after it (slod_plan_join / slod_plan_status do that)
+      slot            = (int)(p->n_exec & 1);
+      hipStream_t own = p->istream[slot];
+      e               = hipEventRecord(p->fork_ev, st);
+      if (e == hipSuccess)
+        e = hipStreamWaitEvent(own, p->fork_ev, 0);
+      st = own;
+    }
+  if (e == hipSuccess)
+    e = hipMemsetAsync(slot ? p->alt.d_status : p->d_status, 0, sizeof(int32_t), st);
+  size_t ci = 0;
   (void)s;
   for (size_t first = 0; first < p->n && e == hipSuccess; first += p->chunk, ++ci)
     e = launch_range(p, first, (int)std::min(p->chunk, p->n - first), d_basis, d_premult, st,
-                     &p->ev[4 * ((p->n_exec % (size_t)p->depth) * p->n_chunks + ci)], true);
+                     &p->ev[4 * ((p->n_exec % (size_t)p->depth) * p->n_chunks + ci)], true, slot);
+  if (e == hipSuccess && p->overlap == 2)
+    {
+      e                 = hipEventRecord(p->done_ev[slot], st);
+      p->inflight[slot] = true;
+    }
   if (e != hipSuccess)
     return hip_fail(h, e, "slod_plan_execute");
   p->ran = true;
   ++p->n_exec;
   return SLOD_OK;
+}
+
+int slod_plan_set_overlap(slod_plan *p, int depth)
+{
+  if (!p || (depth != 1 && depth != 2))
+    return SLOD_ERR_ARGUMENT;
+  slod_handle *h = p->h;
+  if (p->n == 0 || depth == p->overlap)
+    return SLOD_OK;
+  (void)hipSetDevice(h->cfg.device);
+  (void)hipDeviceSynchronize();
+  if (depth == 1)
+    {
+      p->overlap = 1; // the second workspace stays allocated until the plan is destroyed
+      return SLOD_OK;
+    }
+  if (p->n_chunks != 1)
+    return fail(h, SLOD_ERR_STATE, "slod_plan_set_overlap: the plan runs in several workspace chunks (they de-phase by themselves)");
+  const bool own_z = p->ws_z != nullptr;
+  const size_t st_slack = (size_t)4 * p->nn_max;
+  bool ok = true;
+  if (!p->alt.ws_st)
+    {
+      ok = ok && hipMalloc((void **)&p->alt.ws_st, (p->chunk * p->st_stride + st_slack) * sizeof(double)) == hipSuccess;
+      ok = ok && hipMalloc((void **)&p->alt.ws_v, std::max<size_t>(1, p->chunk * p->v_stride) * sizeof(double)) == hipSuccess;
+      ok = ok && hipMalloc((void **)&p->alt.ws_x_alloc, (p->chunk * p->x_stride + 2 * p->guard) * sizeof(double)) == hipSuccess;
+      if (own_z)
+        ok = ok && hipMalloc((void **)&p->alt.ws_z, (p->chunk * p->x_stride + p->guard) * sizeof(double)) == hipSuccess;
+      ok = ok && hipMalloc((void **)&p->alt.ws_m, p->chunk * (size_t)p->nc_max * p->nc_max * sizeof(double)) == hipSuccess;
+      ok = ok && hipMalloc((void **)&p->alt.d_status, sizeof(int32_t)) == hipSuccess;
+      ok = ok && hipMemset(p->alt.ws_st, 0, (p->chunk * p->st_stride + st_slack) * sizeof(double)) == hipSuccess;
+      ok = ok && hipMemset(p->alt.ws_x_alloc, 0, (p->chunk * p->x_stride + 2 * p->guard) * sizeof(double)) == hipSuccess;
+      if (own_z)
+        ok = ok && hipMemset(p->alt.ws_z, 0, (p->chunk * p->x_stride + p->guard) * sizeof(double)) == hipSuccess;
+      ok = ok && hipMemset(p->alt.d_status, 0, sizeof(int32_t)) == hipSuccess;
+      p->alt.ws_x = p->alt.ws_x_alloc ? p->alt.ws_x_alloc + p->guard : nullptr;
+      for (int k = 0; k < 2 && ok; ++k)
+        {
+          ok = ok && hipStreamCreateWithFlags(&p->istream[k], hipStreamNonBlocking) == hipSuccess;
+          ok = ok && hipEventCreateWithFlags(&p->done_ev[k], hipEventDisableTiming) == hipSuccess;
+        }
+      ok = ok && hipEventCreateWithFlags(&p->fork_ev, hipEventDisableTiming) == hipSuccess;
+    }
+  if (!ok)
+    return hip_fail(h, hipGetLastError(), "slod_plan_set_overlap: device allocation");
+  p->overlap = 2;
+  p->n_exec  = 0; // the profile slots start over
+  return SLOD_OK;
+}
+
+int slod_plan_join(slod_plan *p, void *hip_stream)
+{
+  if (!p)
+    return SLOD_ERR_ARGUMENT;
+  if (p->overlap != 2 && !p->inflight[0] && !p->inflight[1])
+    return SLOD_OK;
+  (void)hipSetDevice(p->h->cfg.device);
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : p->h->stream;
+  hipError_t  e  = hipSuccess;
+  for (int k = 0; k < 2 && e == hipSuccess; ++k)
+    if (p->inflight[k])
+      e = hipStreamWaitEvent(st, p->done_ev[k], 0);
+  return e == hipSuccess ? SLOD_OK : hip_fail(p->h, e, "slod_plan_join");
 }
 
 int slod_plan_patch_layout(slod_plan *p, size_t k, int launch_order, slod_patch_info *info, uint32_t *plan_index)
@@ -801,10 +916,14 @@ int slod_plan_status(slod_plan *p)
     return SLOD_ERR_ARGUMENT;
   if (!p->ran || p->n == 0)
     return SLOD_OK;
-  int32_t    st = 0;
+  int32_t    st = 0, st2 = 0;
   hipError_t e  = hipDeviceSynchronize();
   if (e == hipSuccess)
     e = hipMemcpy(&st, p->d_status, sizeof(st), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && p->alt.d_status)
+    e = hipMemcpy(&st2, p->alt.d_status, sizeof(st2), hipMemcpyDeviceToHost);
+  st |= st2;
+  p->inflight[0] = p->inflight[1] = false;
   if (e != hipSuccess)
     return hip_fail(p->h, e, "slod_plan_status");
   if (st)

@@ -88,6 +88,8 @@ def load():
     lib.slod_plan_profile.argtypes = [vp, C.c_int]
     lib.slod_plan_status.argtypes = [vp]
     lib.slod_plan_patch_layout.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(PatchInfo), u32p]
+    lib.slod_plan_set_overlap.argtypes = [vp, C.c_int]
+    lib.slod_plan_join.argtypes = [vp, vp]
     lib.slod_plan_diagnostics.argtypes = [vp, C.POINTER(PatchDiag), C.c_size_t]
     lib.slod_compute_basis.argtypes = [vp, u32p, C.c_size_t, dp, dp, u64p]
     lib.slod_comm_last_error.restype = C.c_char_p
@@ -208,6 +210,13 @@ class Plan:
 
     def status(self):
         self.slod._check(self.lib.slod_plan_status(self.p))
+
+    def set_overlap(self, depth):
+        """depth 2: consecutive executes overlap on two internal streams (join() / status() order the caller after them)."""
+        self.slod._check(self.lib.slod_plan_set_overlap(self.p, depth))
+
+    def join(self, stream_ptr=None):
+        self.slod._check(self.lib.slod_plan_join(self.p, stream_ptr))
 
     def patch_layout(self, k, launch_order=False):
         """(PatchInfo, plan_index) of the k-th descriptor the kernels launch with (device read-back)."""

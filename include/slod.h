@@ -135,6 +135,17 @@ int slod_plan_profile(slod_plan *p, int depth);
  * slod_plan_execute; slod_plan_execute_allgather records none: SLOD_ERR_STATE after it);
  * synchronises.  ms[0] assemble, ms[1] patch solve, ms[2] selection */
 int slod_plan_kernel_ms(slod_plan *p, float ms[3]);
+/* Overlap of consecutive executes inside the library (depth 1 = default, 2).  All workgroups of a step
+ * start together and run through the same phases in lock-step; two steps half a phase apart fill each
+ * other's idle issue slots (+14..16 % patches/s at BASELINE config C2).  With depth 2 the plan owns a
+ * second workspace and two internal streams; slod_plan_execute alternates between them.  Each execute
+ * is ordered AFTER everything submitted to its hip_stream so far, but hip_stream is NOT ordered after
+ * the execute: call slod_plan_join(plan, stream) to make a stream wait for the executes in flight
+ * (asynchronous), or slod_plan_status (synchronises).  Plans that run in several workspace chunks are
+ * refused (SLOD_ERR_STATE): their launches de-phase by themselves.  Reference: the serial patch loop
+ * LOD.cc:345-767 has no counterpart. */
+int slod_plan_set_overlap(slod_plan *p, int depth);
+int slod_plan_join(slod_plan *p, void *hip_stream);
 /* The k-th patch descriptor the plan's kernels LAUNCH with, read back from the device (the descriptors
  * are produced by a device kernel from the grid scalars: create_patches + create_mesh_for_patch,
  * LOD.cc:122-244,770-858).  launch_order = 0: the caller's order; 1: the balanced launch order

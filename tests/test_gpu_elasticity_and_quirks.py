@@ -496,3 +496,57 @@ def test_elasticity_c4_sample_with_projection_quirk(so, dist):
     for k, pid in enumerate(ids):
         worst = max(worst, _check_patch(so, cfg, fields, int(pid), basis, premult, int(offs[k]), "C4 quirk")[0])
     print("C4 with projection quirk, %s: %d patches, worst |dphi| %.3e" % (dist, len(ids), worst))
+
+
+def test_overlapped_executes_inside_the_library(so):
+    """slod_plan_set_overlap(plan, 2): consecutive slod_plan_execute calls run on two internal streams with
+    two workspaces.  Outputs bit-identical to the serial plan whatever buffer each execute writes;
+    slod_plan_join orders a stream after them; status and decisions as in the serial run; plans in
+    several workspace chunks refuse the mode."""
+    import slod_amd
+    import torch
+    cfg, g = _mk(so, nref=4, n_sub=4, oversampling=2, stabilize=1)
+    fields = make_fields(so, cfg, "D1e4")
+    _upload(g, fields)
+    ids = np.arange(g.num_patches, dtype=np.uint32)
+    plan = g.plan(ids)
+    dev = torch.device("cuda", 0)
+    n = len(ids) * plan.stride
+    ref_b = torch.zeros(n, dtype=torch.float64, device=dev)
+    ref_q = torch.zeros_like(ref_b)
+    plan.execute(ref_b.data_ptr(), ref_q.data_ptr())
+    plan.status()
+    d_ref = [(d.path, d.n_cut, d.n_dropped) for d in plan.diagnostics()]
+    plan.set_overlap(2)
+    outs = [(torch.zeros_like(ref_b), torch.zeros_like(ref_b)) for _ in range(3)]
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for k in range(7):
+            b, q = outs[k % 3]
+            b.zero_()                              # stream work the execute must be ordered after
+            plan.execute(b.data_ptr(), q.data_ptr(), s.cuda_stream)
+        plan.join(s.cuda_stream)
+        sums = [float(b.sum()) for b, _ in outs]   # ordered after the executes by the join
+    torch.cuda.synchronize()
+    plan.status()
+    for b, q in outs:
+        assert torch.equal(b, ref_b) and torch.equal(q, ref_q)
+    assert all(abs(x - float(ref_b.sum())) < 1e-9 for x in sums)
+    assert [(d.path, d.n_cut, d.n_dropped) for d in plan.diagnostics()] == d_ref
+    assert plan.kernel_ms()[1] > 0.0
+    plan.set_overlap(1)
+    b, q = outs[0]
+    b.zero_()
+    plan.execute(b.data_ptr(), q.data_ptr())
+    plan.status()
+    assert torch.equal(b, ref_b)
+
+
+def test_overlap_refused_for_chunked_plans(so, monkeypatch):
+    import slod_amd
+    monkeypatch.setenv("SLOD_WORKSPACE_MB", "2")
+    cfg, g = _mk(so, nref=4, n_sub=4, oversampling=2, stabilize=1)
+    plan = g.plan(np.arange(g.num_patches, dtype=np.uint32))
+    with pytest.raises(slod_amd.SlodError) as e:
+        plan.set_overlap(2)
+    assert e.value.code == -4
