@@ -82,7 +82,7 @@ bool slod_choose_solver(int S, int n_sub, int m_max, int L_max, int nc_max, int 
       c.kind          = SLOD_K_TW;
       c.lds           = slod_solve_tw_lds_bytes(S, m_max, nc_max);
       c.v_line_pad    = 8 * wt;
-      c.v_line_elems  = (size_t)36 * wt * wt; // symmetric: lane tiles on or above the diagonal
+      c.v_line_elems  = (size_t)64 * wt * wt; // the 8 x 8 lane tiles, both triangles
       c.fuse_assemble = (S == 1 && t.fuse_assemble) ? 1 : 0;
       // the selection stage runs in the same launch (scalar problems) while four workgroups
       // still fit a CU

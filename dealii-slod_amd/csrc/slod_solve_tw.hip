@@ -22,7 +22,10 @@ namespace
     const SlodPatchDesc d = A.desc[blockIdx.x];
     constexpr int       W = 2 * S - 1, BW = 2 * W + 1, MP = 8 * T;
     constexpr int       BWP = BW + 1, BROWS = MP + 2 * W, bsz = (BROWS * BWP + 1) & ~1;
-    const int           tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int           tid = threadIdx.x, wave = tid >> 6;
+    // (not const: the step loops of the forward sweep pass it through an empty asm each iteration, so
+    // that per-lane addresses are recomputed there instead of being hoisted out of the loop and spilled)
+    int                 lane = tid & 63;
     const int           chain = wave & 1;
     const bool          is_gj = wave < 2;
     const int           m = d.m, L = d.L, nc = d.n_c, n = A.n_sub;
@@ -55,28 +58,24 @@ namespace
     double       *vg    = A.vinv + (size_t)blockIdx.x * A.v_stride;
     double       *xg    = A.xs + (size_t)blockIdx.x * A.x_stride; // X, column order of P^T
     double       *zg    = A.zs + (size_t)blockIdx.x * A.x_stride; // Z, each chain's own column order
-    // V of a line is symmetric: only the 36 lane tiles on or above the diagonal of the 8 x 8 lane
-    // grid are stored, tile (a, b >= a) as a contiguous T x T block at index a*8 - a(a-1)/2 + b - a
-    const size_t  vline = (size_t)36 * T * T, xline = (size_t)mm * ncg;
-    auto          vtile = [](int a, int b) { return a * 8 - (a * (a - 1)) / 2 + (b - a); };
+    // V of a line: the 8 x 8 lane tiles of the Gauss-Jordan wave, tile (a, b) as a contiguous T x T
+    // block (row major) at index 8 a + b.  Both triangles are stored: a row of the MFMA A operand is then
+    // T contiguous doubles per lane tile (wide loads off two base addresses); reading the lower triangle
+    // transposed out of a packed upper one cost ten scattered loads and their 64-bit addresses per row tile.
+    const size_t  vline = (size_t)64 * T * T, xline = (size_t)mm * ncg;
     // MFMA A operand from that storage: lane (r = lane & 15, kq = lane >> 4) of step kk = g T + kr
     // takes V[16 ti + r][k], k = T (kq + 4 g) + kr -- the K index is permuted so that the lane tile
     // column of k is a per-lane constant plus 4 g and kr is a compile-time constant; the B operand
-    // uses the same k (row k of the LDS block).  Tiles below the diagonal are read transposed.
+    // uses the same k (row k of the LDS block).
     auto load_A = [&](const double *vl, int ti, double (&dst)[MP / 4]) __attribute__((always_inline)) {
-      const int row = min(16 * ti + (lane & 15), MP - 1);
-      const int rt = row / T, rr = row - rt * T, kq = lane >> 4;
+      const int     row = min(16 * ti + (lane & 15), MP - 1);
+      const int     rt = row / T, rr = row - rt * T, kq = lane >> 4;
+      const double *base = vl + (rt * 8 + kq) * (T * T) + rr * T;
 #pragma unroll
       for (int g = 0; g < 2; ++g)
-        {
-          const int     kt = kq + 4 * g;
-          const bool    up = rt <= kt;
-          const double *base = vl + vtile(up ? rt : kt, up ? kt : rt) * (T * T) + (up ? rr * T : rr);
-          const int     step = up ? 1 : T;
 #pragma unroll
-          for (int kr = 0; kr < T; ++kr)
-            dst[g * T + kr] = base[kr * step];
-        }
+        for (int kr = 0; kr < T; ++kr)
+          dst[g * T + kr] = base[g * 4 * T * T + kr];
     };
     // row of the B operand (LDS block) of step kk for this lane: T (kq + 4 g) + kr
     auto brow = [&](int kk) { return T * ((lane >> 4) + 4 * (kk / T)) + kk % T; };
@@ -98,6 +97,11 @@ namespace
       }
     if ((SLOD_DG(A, (1 << 20))) && lane == 0 && A.nc_max * A.nc_max >= 24) // SIMD of each wave (HW_ID bits 5:4)
       A.ms[(size_t)blockIdx.x * A.nc_max * A.nc_max + 20 + wave] = (double)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+    auto tstamp = [&](int k) {
+      if ((SLOD_DG(A, (1 << 20))) && tid == 0 && A.nc_max * A.nc_max >= 48)
+        A.ms[(size_t)blockIdx.x * A.nc_max * A.nc_max + 32 + k] = (double)wall_clock64();
+    };
+    tstamp(0);
     // Fused stencil assembly: the workgroup builds the stencil planes of its own patch (k_assemble
     // as a device function), saving a launch and its tail; the planes still go through the
     // workspace, which the band fetches and the selection stage read back
@@ -170,13 +174,14 @@ namespace
       put_step(1, t0, 128);
     }
     __syncthreads();
+    tstamp(1);
 
     // ------------------------------ forward elimination ---------------------------
     if (is_gj)
       {
         __builtin_amdgcn_s_setprio(3);
-        const int gy = lane >> 3, gx = lane & 7;
-        double    a[T][T];
+        int    gy = lane >> 3, gx = lane & 7;
+        double a[T][T];
         // neighbour lane in the same lane-grid row through DPP (row_shr:1 / row_shl:1, no LDS trip):
         // the lanes at the ends of an 8-lane grid row receive a foreign (finite) value that only
         // ever meets a zero band entry
@@ -190,7 +195,72 @@ namespace
           const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x101, 0xf, 0xf, true);
           return __hiloint2double(hi, lo);
         };
+        // Scalar problems (W == 1): the band entries a lane needs do not depend on the tile row (column
+        // pass) resp. tile column (row pass): 3T values each, fetched from LDS ONCE in one batch.  The
+        // generic version below re-reads them per tile row under its per-row scheduling barriers and
+        // ends up with one exposed LDS round trip per FMA pair (measured: 9.2 us per step, tools/tw_timeline.py).
+        auto next_S_w1 = [&](const double *Tsrc, const double *Bl) __attribute__((always_inline)) {
+          const double *cbp = Bl + (T * gx) * BWP + 2;
+          const double *dbp = Bl + (T * gy) * BWP + 2;
+          double        cb[T][3], db[T][3];
+#pragma unroll
+          for (int tb = 0; tb < T; ++tb)
+#pragma unroll
+            for (int f = 0; f < 3; ++f)
+              {
+                cb[tb][f] = cbp[(tb + f) * BWP - f];
+                db[tb][f] = dbp[(tb + f) * BWP - f];
+              }
+          // column pass: a <- -(a B) over the lane-grid row (neighbour lanes through DPP)
+#pragma unroll
+          for (int ta = 0; ta < T; ++ta)
+            {
+              double ext[T + 2];
+              ext[0]     = -dpp_from_prev(a[ta][T - 1]);
+              ext[T + 1] = -dpp_from_next(a[ta][0]);
+#pragma unroll
+              for (int tb = 0; tb < T; ++tb)
+                ext[1 + tb] = -a[ta][tb];
+#pragma unroll
+              for (int tb = 0; tb < T; ++tb)
+                a[ta][tb] = fma(ext[tb + 2], cb[tb][2], fma(ext[tb + 1], cb[tb][1], ext[tb] * cb[tb][0]));
+            }
+          // row pass: a <- T - B^T a over the lane-grid column (neighbour lanes through bpermute, one batch)
+          double up[T], dn[T];
+#pragma unroll
+          for (int tb = 0; tb < T; ++tb)
+            {
+              up[tb] = __shfl(a[T - 1][tb], lane - 8, 64);
+              dn[tb] = __shfl(a[0][tb], lane + 8, 64);
+            }
+#pragma unroll
+          for (int tb = 0; tb < T; ++tb)
+            {
+              const int j = T * gx + tb;
+              double    tv[T], ext[T + 2];
+#pragma unroll
+              for (int ta = 0; ta < T; ++ta)
+                {
+                  const int      i  = T * gy + ta;
+                  const unsigned oi = (unsigned)(j - i + 1);
+                  tv[ta]            = Tsrc[(i + 1) * BWP + (oi < 3u ? oi : 3u)];
+                }
+              ext[0]     = up[tb];
+              ext[T + 1] = dn[tb];
+#pragma unroll
+              for (int ta = 0; ta < T; ++ta)
+                ext[1 + ta] = a[ta][tb];
+#pragma unroll
+              for (int ta = 0; ta < T; ++ta)
+                a[ta][tb] = fma(-ext[ta + 2], db[ta][2], fma(-ext[ta + 1], db[ta][1], fma(-ext[ta], db[ta][0], tv[ta])));
+            }
+        };
         auto next_S = [&](const double *Tsrc, const double *Bl) __attribute__((always_inline)) {
+          if (W == 1)
+            {
+              next_S_w1(Tsrc, Bl);
+              return;
+            }
           const double *cbp = Bl + (T * gx) * BWP + 2 * W;
 #pragma unroll
           for (int ta = 0; ta < T; ++ta)
@@ -313,15 +383,12 @@ namespace
         };
         // tile <-> global [MP][MP] block (V lines, and the meeting-line contribution of chain 1)
         auto store_tile = [&](double *dst, double sign) __attribute__((always_inline)) {
-          if (gy <= gx)
-            {
-              double *tp = dst + vtile(gy, gx) * (T * T);
+          double *tp = dst + (gy * 8 + gx) * (T * T);
 #pragma unroll
-              for (int ta = 0; ta < T; ++ta)
+          for (int ta = 0; ta < T; ++ta)
 #pragma unroll
-                for (int tb = 0; tb < T; ++tb)
-                  tp[ta * T + tb] = sign * a[ta][tb];
-            }
+            for (int tb = 0; tb < T; ++tb)
+              tp[ta * T + tb] = sign * a[ta][tb];
         };
         // a = T of the chain's first line (chain 1 without lines contributes nothing)
 #pragma unroll
@@ -334,34 +401,54 @@ namespace
               const double   v  = Tf[(i + W) * BWP + (oi < (unsigned)BW ? oi : (unsigned)BW)];
               a[ta][tb]         = (chain == 1 && nmy == 0) ? 0.0 : v;
             }
+        double acc_t[4] = {0.0, 0.0, 0.0, 0.0}; // diag: sweep, store + next_S, barrier wait, store alone
         for (int t = 0; t < nstp; ++t)
           {
             const bool active = t < nmy;
+            asm volatile("" : "+v"(lane));
+            gy = lane >> 3;
+            gx = lane & 7;
+            const long long c0 = (SLOD_DG(A, (1 << 20))) ? wall_clock64() : 0;
+            long long       c1 = c0, c2 = c0;
             if (active)
               {
                 sweep();
+                c1 = (SLOD_DG(A, (1 << 20))) ? wall_clock64() : 0;
                 if (!(SLOD_DG(A, 32768)))
                   store_tile(vg + (size_t)line_of(chain, t) * vline, -1.0);
+                if (SLOD_DG(A, (1 << 20)))
+                  acc_t[3] += (double)(wall_clock64() - c1);
                 // Schur complement of the next line (the meeting line after the last step), in
                 // registers: overlaps the drain of the V stores before the barrier
                 if (!(SLOD_DG(A, 16384)))
                   next_S((t & 1) ? Tn1 : Tn0, Bbuf(Bc0, t));
+                c2 = (SLOD_DG(A, (1 << 20))) ? wall_clock64() : 0;
               }
             __syncthreads(); // A_t: V of step t is in the workspace, bands of step t+1 are in LDS
+            if (SLOD_DG(A, (1 << 20)))
+              {
+                const long long c3 = wall_clock64();
+                acc_t[0] += (double)(c1 - c0);
+                acc_t[1] += (double)(c2 - c1);
+                acc_t[2] += (double)(c3 - c2);
+              }
           }
+        if ((SLOD_DG(A, (1 << 20))) && tid == 0 && A.nc_max * A.nc_max >= 48)
+          for (int k = 0; k < 4; ++k)
+            A.ms[(size_t)blockIdx.x * A.nc_max * A.nc_max + 40 + k] = acc_t[k];
+        tstamp(2);
         // the meeting line: a0 = T_mid - W_0, a1 = -W_1
         if (chain == 1)
           store_tile(vg + (size_t)mid * vline, 1.0);
         __syncthreads(); // M1: chain 1's contribution is in the workspace
         if (chain == 0)
           {
-            const bool    up = gy <= gx;
-            const double *w1 = vg + (size_t)mid * vline + vtile(up ? gy : gx, up ? gx : gy) * (T * T);
+            const double *w1 = vg + (size_t)mid * vline + (gy * 8 + gx) * (T * T);
 #pragma unroll
             for (int ta = 0; ta < T; ++ta)
 #pragma unroll
               for (int tb = 0; tb < T; ++tb)
-                a[ta][tb] += w1[up ? ta * T + tb : tb * T + ta];
+                a[ta][tb] += w1[ta * T + tb];
             sweep();
             store_tile(vg + (size_t)mid * vline, -1.0);
           }
@@ -382,48 +469,96 @@ namespace
         // zprev that holds it (nullptr: r), valid only if that column was active at step tlim of the
         // chain that wrote it (zact, by zprev column)
         auto build_R = [&](int line, const double *Bprev, const double *zprev, int zstride, bool with_F, bool add, int ncols,
-                           const int *cmap, const int *zmap, const int *zact, int tlim) __attribute__((always_inline)) {
+                           const int *cmap, const int *zmap, const int *zact, int tlim, bool zlds) __attribute__((always_inline)) {
           if (SLOD_DG(A, 2))
             return;
-          const int half = lane >> 5, i_lo = half ? (m + 1) / 2 : 0, i_hi = half ? m : (m + 1) / 2;
-          for (int r = lane & 31; r < ncols; r += 32)
+          // Lane (g, cq) of the 8 x 8 lane grid owns rows T g .. T g + T - 1 of the columns cq + 8 k.
+          // Everything a lane needs from the workspace (the T + 2W rows of Z(prev) around its rows, CP
+          // columns per pass) is requested in one batch, branch-free: one exposed workspace round trip
+          // per pass.  (A sliding window down a column, one load and three dependent LDS reads per row,
+          // cost 10 us per step at C2 -- more than the Gauss-Jordan sweep it has to hide behind.)
+          constexpr int CP = 2;
+          const int     g = lane >> 3, cq = lane & 7;
+          const double *zp = zprev ? zprev : zg;
+          for (int r0 = 0; r0 < ncols; r0 += 8 * CP)
             {
-              const int  c = cmap ? cmap[r] : r, zc = zmap ? zmap[r] : r;
-              const bool zok = zprev && zact[zc] <= tlim;
-              const int  kxn = colk[c] * n, kyn = colk[A.nc_max + c] * n;
-              double     win[BW];
+              double win[CP][T + 2 * W];
+              int    kxn[CP], kyn[CP], cc[CP];
+              bool   valid[CP];
 #pragma unroll
-              for (int e = 0; e < BW; ++e)
+              for (int k = 0; k < CP; ++k)
                 {
-                  const int p = i_lo + e - W;
-                  win[e]      = (zok && p >= 0 && p < m) ? zprev[p * zstride + zc] : 0.0;
-                }
-              for (int i = i_lo; i < i_hi; ++i)
-                {
-                  const int pn = i + 1 + W; // row entering the window for the next i
-                  const double znext = (zok && pn < m) ? zprev[pn * zstride + zc] : 0.0;
-                  double       v     = add ? Rb[i * ncs + r] : 0.0;
-                  if (with_F)
+                  const int r  = r0 + 8 * k + cq;
+                  valid[k]     = r < ncols;
+                  const int rc = valid[k] ? r : 0;
+                  const int c = cmap ? cmap[rc] : rc, zc = zmap ? zmap[rc] : rc;
+                  const bool zok = valid[k] && zprev && zact[zc] <= tlim;
+                  cc[k]  = c;
+                  kxn[k] = colk[c] * n;
+                  kyn[k] = colk[A.nc_max + c] * n;
+                  if (zlds) // Z(prev) is what the GEMM of the previous step left in the LDS block (row stride ncs)
                     {
-                      const int pos = i / S, comp = i - pos * S;
-                      const int ix = tr ? line + 1 : pos + 1, iy = tr ? pos + 1 : line + 1;
-                      const int jx = ix - kxn, jy = iy - kyn;
-                      if (jx >= 0 && jx <= n && jy >= 0 && jy <= n)
+#pragma unroll
+                      for (int e = 0; e < T + 2 * W; ++e)
                         {
-                          if (S == 1)
-                            v += A.scale * (((jx == 0 || jx == n) ? 1.0 : 2.0) * ((jy == 0 || jy == n) ? 1.0 : 2.0));
-                          else
-                            v += A.scale * pt_weight<S>(d, n, A.quirk, ix, iy, comp, c);
+                          const int    p   = T * g + e - W;
+                          const bool   inb = zok && p >= 0 && p < m;
+                          const double z   = Rb[(inb ? p : 0) * ncs + (inb ? zc : 0)];
+                          win[k][e]        = inb ? z : 0.0;
                         }
                     }
+                  else
+                    {
+#pragma unroll
+                      for (int e = 0; e < T + 2 * W; ++e)
+                        {
+                          const int    p   = T * g + e - W;
+                          const bool   inb = zok && p >= 0 && p < m;
+                          const double z   = zp[(inb ? p : 0) * zstride + (inb ? zc : 0)];
+                          win[k][e]        = inb ? z : 0.0;
+                        }
+                    }
+                }
+              if (zlds) // the block is rewritten in place: every lane has its window before any lane writes
+                {
+                  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                  __builtin_amdgcn_wave_barrier();
+                  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+#pragma unroll
+              for (int ta = 0; ta < T; ++ta)
+                {
+                  const int i = T * g + ta;
+                  double    bnd[BW];
 #pragma unroll
                   for (int e = 0; e < BW; ++e) // B[p][i], p = i+e-W (zero padded band rows)
-                    v = fma(-Bprev[(i + e) * BWP + (2 * W - e)], win[e], v);
-                  Rb[i * ncs + r] = v;
+                    bnd[e] = Bprev[(i + e) * BWP + (2 * W - e)];
+                  const int pos = i / S, comp = i - pos * S;
+                  const int ix = tr ? line + 1 : pos + 1, iy = tr ? pos + 1 : line + 1;
 #pragma unroll
-                  for (int e = 0; e + 1 < BW; ++e)
-                    win[e] = win[e + 1];
-                  win[BW - 1] = znext;
+                  for (int k = 0; k < CP; ++k)
+                    {
+                      const int r = r0 + 8 * k + cq;
+                      const bool wr = valid[k] && i < m;
+                      double    v = (add && wr) ? Rb[i * ncs + r] : 0.0;
+                      if (with_F)
+                        {
+                          const int  jx = ix - kxn[k], jy = iy - kyn[k];
+                          const bool in = jx >= 0 && jx <= n && jy >= 0 && jy <= n;
+                          if (S == 1)
+                            {
+                              const double w = ((jx == 0 || jx == n) ? 1.0 : 2.0) * ((jy == 0 || jy == n) ? 1.0 : 2.0);
+                              v += in ? A.scale * w : 0.0;
+                            }
+                          else if (in)
+                            v += A.scale * pt_weight<S>(d, n, A.quirk, ix, iy, comp, cc[k]);
+                        }
+#pragma unroll
+                      for (int e = 0; e < BW; ++e)
+                        v = fma(-bnd[e], win[k][ta + e], v);
+                      if (wr)
+                        Rb[i * ncs + r] = v;
+                    }
                 }
             }
         };
@@ -471,7 +606,111 @@ namespace
                 av[kk] = an[kk];
             }
         };
-        int na = 0; // active columns (chain order) at the step being processed
+        // The same product for a line whose accumulators fit in registers (TI row tiles x 2 column
+        // tiles): Z goes to the workspace (the backward sweep reads it) AND replaces the RHS block in
+        // LDS, where the next step's build_R takes its windows from -- no workspace round trip between
+        // two steps of the chain.  av: row tile 0 of V, requested by the caller before it built the block.
+        constexpr int TI = (MP + 15) / 16;
+        auto gemm_Z_keep = [&](int line, int ncols, double *xl, double (&av)[MP / 4]) __attribute__((always_inline)) {
+          const double *vl = vg + (size_t)line * vline;
+          const bool    two = ncols > 16;
+          // the B operands of a lane do not depend on the row tile: read once, then the block is free
+          double        bq[2][MP / 4];
+          const double *bp = Rb + (lane & 15);
+#pragma unroll
+          for (int kk = 0; kk < MP / 4; ++kk)
+            {
+              bq[0][kk] = bp[brow(kk) * ncs];
+              bq[1][kk] = bp[brow(kk) * ncs + 16];
+            }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          double an[MP / 4];
+#pragma unroll
+          for (int ti = 0; ti < TI; ++ti)
+            {
+              if (ti < tiles_i)
+                {
+                  if (ti + 1 < TI && ti + 1 < tiles_i)
+                    load_A(vl, ti + 1, an);
+                  double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                  for (int kk = 0; kk < MP / 4; ++kk)
+                    {
+                      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bq[0][kk], acc0, 0, 0, 0);
+                      if (two)
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bq[1][kk], acc1, 0, 0, 0);
+                    }
+#pragma unroll
+                  for (int r = 0; r < 4; ++r)
+                    {
+                      const int row = 16 * ti + (lane >> 4) + 4 * r, col = lane & 15;
+                      if (row < m && col < ncols)
+                        {
+                          xl[row * ncols + col] = acc0[r];
+                          Rb[row * ncs + col]   = acc0[r];
+                        }
+                      if (two && row < m && col + 16 < ncols)
+                        {
+                          xl[row * ncols + col + 16] = acc1[r];
+                          Rb[row * ncs + col + 16]   = acc1[r];
+                        }
+                    }
+                  if (ti + 1 < TI)
+                    {
+#pragma unroll
+                      for (int kk = 0; kk < MP / 4; ++kk)
+                        av[kk] = an[kk];
+                    }
+                }
+            }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        };
+        // put_step in two halves for this wave: the stencil values of step stp are requested before the
+        // RHS block / GEMM work of the step (branch-free, so that the loads really are in flight) and
+        // land in the band buffers after it
+        constexpr int NBQ = (MP * BW + 63) / 64;
+        double        tq[NBQ], bq_[NBQ];
+        auto fetch_step = [&](int stp) __attribute__((always_inline)) {
+          const bool on = stp < nmy;
+          const int  lT = line_of(chain, stp + 1), lB = line_of(chain, stp);
+          const bool with_T = !(chain == 1 && stp + 1 == nmy);
+#pragma unroll
+          for (int q = 0; q < NBQ; ++q)
+            {
+              const int  idx = lane + 64 * q, i = idx / BW, oi = idx - i * BW, o = oi - W, j = i + o;
+              const int  pi = i / S, ci = i - pi * S, pj = j / S, cj = j - pj * S, dp = pj - pi;
+              const bool ok = on && idx < m * BW && j >= 0 && j < m && dp >= -1 && dp <= 1;
+              // (same indexing as coupling<S>, with the address clamped instead of a branch)
+              const int ixT = tr ? lT + 1 : pi + 1, iyT = tr ? pi + 1 : lT + 1;
+              const int ixB = tr ? lB + 1 : pi + 1, iyB = tr ? pi + 1 : lB + 1;
+              const int dirT = (tr ? dp : 0) * 3 + (tr ? 0 : dp) + 4;
+              const int dirB = ((tr ? dp : dl) + 1) * 3 + (tr ? dl : dp) + 1;
+              const double vT = st[ok ? (size_t)((dirT * S + ci) * S + cj) * A.nn_max + ixT + iyT * npx : 0];
+              const double vB = st[ok ? (size_t)((dirB * S + ci) * S + cj) * A.nn_max + ixB + iyB * npx : 0];
+              tq[q]  = (ok && with_T) ? vT : 0.0;
+              bq_[q] = ok ? vB : 0.0;
+            }
+        };
+        auto store_step = [&](int stp) __attribute__((always_inline)) {
+          if (stp >= nmy)
+            return;
+          double *Tdst = (stp & 1) ? Tn1 : Tn0, *Bdst = Bbuf(Bc0, stp);
+#pragma unroll
+          for (int q = 0; q < NBQ; ++q)
+            {
+              const int idx = lane + 64 * q, i = idx / BW, oi = idx - i * BW;
+              if (idx < m * BW)
+                {
+                  Tdst[(i + W) * BWP + oi] = tq[q];
+                  Bdst[(i + W) * BWP + oi] = bq_[q];
+                }
+            }
+        };
+        double acc_h[4] = {0.0, 0.0, 0.0, 0.0}; // diag: fwd_step, put_step, barrier wait, build_R alone
+        int  na = 0;           // active columns (chain order) at the step being processed
+        bool z_in_lds = false; // the LDS block holds Z of the chain's previous line (gemm_Z_keep)
         // RHS block and Z of step tl: active columns only; Z(prev) of a column that became active
         // at this very step was never written (it is zero)
         // A line of Z is stored compactly: [m][na(line)], so only whole cache lines of active data move
@@ -480,22 +719,57 @@ namespace
           while (na < nc && act[na] <= tl)
             ++na;
           const int line = line_of(chain, tl);
+          const long long b0 = (SLOD_DG(A, (1 << 20))) ? wall_clock64() : 0;
+          const bool keep = TI <= 3 && na <= 32 && !(SLOD_DG(A, 8));
+          if (keep)
+            {
+              double av[MP / 4];
+              load_A(vg + (size_t)line * vline, 0, av); // V(line) became visible at the last barrier
+              build_R(line, Bbuf(Bc0, tl - 1), tl > 0 ? zg + (size_t)line_of(chain, tl - 1) * xline : nullptr, na_prev,
+                      true, false, na, perm, nullptr, act, tl - 1, z_in_lds);
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              if (SLOD_DG(A, (1 << 20)))
+                acc_h[3] += (double)(wall_clock64() - b0);
+              gemm_Z_keep(line, na, zg + (size_t)line * xline, av);
+              z_in_lds = true;
+              return;
+            }
           build_R(line, Bbuf(Bc0, tl - 1), tl > 0 ? zg + (size_t)line_of(chain, tl - 1) * xline : nullptr, na_prev, true,
-                  false, na, perm, nullptr, act, tl - 1);
+                  false, na, perm, nullptr, act, tl - 1, false);
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
+          if (SLOD_DG(A, (1 << 20)))
+            acc_h[3] += (double)(wall_clock64() - b0);
           gemm_Z(line, na, zg + (size_t)line * xline, na);
+          z_in_lds = false;
         };
         for (int t = 0; t < nstp; ++t)
           {
             // line(t-1): its V became visible at A_{t-1}; the coupling line(t-2) -> line(t-1) is the
             // B band of step t-2
+            asm volatile("" : "+v"(lane));
+            const long long c0 = (SLOD_DG(A, (1 << 20))) ? wall_clock64() : 0;
+            if (t > 0 && !(SLOD_DG(A, 32)))
+              fetch_step(t + 1);
             if (t > 0 && t - 1 < nmy)
               fwd_step(t - 1);
+            const long long c1 = (SLOD_DG(A, (1 << 20))) ? wall_clock64() : 0;
             if (t > 0 && !(SLOD_DG(A, 32)))
-              put_step(t + 1, lane, 64); // bands the GJ wave needs after its next sweep
+              store_step(t + 1); // bands the GJ wave needs after its next sweep
+            const long long c2 = (SLOD_DG(A, (1 << 20))) ? wall_clock64() : 0;
             __syncthreads(); // A_t
+            if (SLOD_DG(A, (1 << 20)))
+              {
+                const long long c3 = wall_clock64();
+                acc_h[0] += (double)(c1 - c0);
+                acc_h[1] += (double)(c2 - c1);
+                acc_h[2] += (double)(c3 - c2);
+              }
           }
+        if ((SLOD_DG(A, (1 << 20))) && tid == 128 && A.nc_max * A.nc_max >= 48)
+          for (int k = 0; k < 4; ++k)
+            A.ms[(size_t)blockIdx.x * A.nc_max * A.nc_max + 44 + k] = acc_h[k];
         // R/Z of the last step (the shorter chain of an even L already did its last line in the loop)
         if (nmy == nstp && nmy > 0)
           fwd_step(nstp - 1);
@@ -514,10 +788,10 @@ namespace
             while (na1 < nc && oact[na1] <= n1 - 1)
               ++na1;
             build_R(mid, B0, n0 > 0 ? zg + (size_t)(mid - 1) * xline : nullptr, na0, true, false, nc, nullptr, inv, act,
-                    n0 - 1);
+                    n0 - 1, false);
             __builtin_amdgcn_wave_barrier();
             if (n1 > 0)
-              build_R(mid, B1, zg + (size_t)(mid + 1) * xline, na1, false, true, nc, nullptr, oinv, oact, n1 - 1);
+              build_R(mid, B1, zg + (size_t)(mid + 1) * xline, na1, false, true, nc, nullptr, oinv, oact, n1 - 1, false);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             gemm_Z(mid, nc, xg + (size_t)mid * xline, ncg); // X_mid
@@ -525,6 +799,7 @@ namespace
         __syncthreads(); // M3
       }
 
+    tstamp(3);
     // ------------------------------ backward substitution -------------------------
     // from the meeting line outwards, both chains at once; each chain = 2 waves (128 threads).
     // Band entries of the next line are fetched (stencil planes, workspace latency) before the
@@ -563,6 +838,17 @@ namespace
           store_B(((nmy - 1) & 1) ? Bc1 : Bc0);
         }
       int nab = nc; // active columns = row stride of the line of Z being read (steps run downwards)
+      // Lines whose accumulators fit in registers keep X of the line just solved in the chain's LDS
+      // block: the band product of the next line takes it from there (in place, as build_R does in the
+      // forward sweep), so a line costs no workspace round trip beyond the prefetched V and Z.
+      constexpr int TIB   = (MP + 15) / 16;
+      const bool    keepb = false && TIB <= 3 && nc <= 32 && !(SLOD_DG(A, 64));
+      if (keepb)
+        for (int idx = t128; idx < m * nc; idx += 128)
+          {
+            const int i = idx / nc, c = idx - i * nc;
+            Rb[i * ncs + c] = xg[(size_t)mid * xline + i * ncg + c];
+          }
       for (int t = tstart; t >= 0; --t)
         {
           while (nab > 0 && act[nab - 1] > t)
@@ -570,9 +856,117 @@ namespace
           const bool    active = t < nmy;
           const int     line = line_of(chain, t), prev = line_of(chain, t + 1); // prev: solved before (mid first)
           const double *Bn = (t & 1) ? Bc1 : Bc0;
-          __syncthreads(); // bands of this line are in LDS, X(prev) is in the workspace
+          asm volatile("" : "+v"(lane));
+          __syncthreads(); // bands of this line are in LDS, X(prev) is in the workspace / the LDS block
           if (active && t > 0)
             fetch_B(line_of(chain, t - 1));
+          if (keepb)
+            {
+              const double *vl = vg + (size_t)line * vline;
+              double       *xl = xg + (size_t)line * xline;
+              const int     g = lane >> 3, cq = lane & 7; // rows T g .. T g + T - 1, columns cq + 8 (2 w2 + k)
+              const int     colw = 16 * w2 + (lane & 15);  // GEMM: wave w2 owns column tile w2
+              double        av[MP / 4], zl[TIB][4], win[2][T + 2 * W];
+              if (active)
+                {
+                  load_A(vl, 0, av);
+                  const double *zrow = zg + (size_t)line * xline;
+                  const int     zc   = colw < nc ? inv[colw] : nc;
+                  const bool    zok  = zc < nab; // the chain order is sorted by the first active step
+#pragma unroll
+                  for (int ti = 0; ti < TIB; ++ti)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                      {
+                        const int    row = 16 * ti + (lane >> 4) + 4 * r;
+                        const bool   ok  = row < m && zok;
+                        const double z   = zrow[ok ? row * nab + zc : 0];
+                        zl[ti][r]        = ok ? z : 0.0;
+                      }
+#pragma unroll
+                  for (int k = 0; k < 2; ++k)
+                    {
+                      const int c = cq + 8 * (2 * w2 + k);
+#pragma unroll
+                      for (int e = 0; e < T + 2 * W; ++e)
+                        {
+                          const int    pr  = T * g + e - W;
+                          const bool   inb = c < nc && pr >= 0 && pr < m;
+                          const double x   = Rb[(inb ? pr : 0) * ncs + (inb ? c : 0)];
+                          win[k][e]        = inb ? x : 0.0;
+                        }
+                    }
+                }
+              __syncthreads(); // every window is in registers: the block may be rewritten
+              if (active)
+                {
+                  // Y = B(line -> prev) X(prev)
+#pragma unroll
+                  for (int ta = 0; ta < T; ++ta)
+                    {
+                      const int i = T * g + ta;
+                      double    bnd[BW];
+#pragma unroll
+                      for (int o = 0; o < BW; ++o)
+                        bnd[o] = Bn[(i + W) * BWP + o];
+#pragma unroll
+                      for (int k = 0; k < 2; ++k)
+                        {
+                          const int c = cq + 8 * (2 * w2 + k);
+                          double    v = 0.0;
+#pragma unroll
+                          for (int o = 0; o < BW; ++o)
+                            v = fma(bnd[o], win[k][ta + o], v);
+                          if (c < nc && i < m)
+                            Rb[i * ncs + c] = v;
+                        }
+                    }
+                }
+              __syncthreads();
+              double bq[MP / 4];
+              if (active)
+                {
+#pragma unroll
+                  for (int kk = 0; kk < MP / 4; ++kk)
+                    bq[kk] = Rb[brow(kk) * ncs + colw];
+                }
+              __syncthreads(); // B operands are in registers: X(line) may replace Y
+              if (active && 16 * w2 < nc)
+                {
+                  double an[MP / 4];
+#pragma unroll
+                  for (int ti = 0; ti < TIB; ++ti)
+                    if (ti < tiles_i)
+                      {
+                        if (ti + 1 < TIB && ti + 1 < tiles_i)
+                          load_A(vl, ti + 1, an);
+                        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int kk = 0; kk < MP / 4; ++kk)
+                          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bq[kk], acc, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                          {
+                            const int row = 16 * ti + (lane >> 4) + 4 * r;
+                            if (row < m && colw < nc)
+                              {
+                                const double x        = zl[ti][r] - acc[r];
+                                xl[row * ncg + colw]  = x;
+                                Rb[row * ncs + colw]  = x;
+                              }
+                          }
+                        if (ti + 1 < TIB)
+                          {
+#pragma unroll
+                            for (int kk = 0; kk < MP / 4; ++kk)
+                              av[kk] = an[kk];
+                          }
+                      }
+                }
+              if (active && t > 0)
+                store_B(((t - 1) & 1) ? Bc1 : Bc0);
+              continue;
+            }
           if (active)
             {
               // Y = B(line -> prev) X(prev): lane = (column r, quarter of the rows), sliding window
