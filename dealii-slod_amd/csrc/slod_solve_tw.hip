@@ -1,4 +1,5 @@
 // k_solve_tw: twisted + wave-specialised patch solve (default).
+#include <type_traits>
 #include "slod_assemble.hip.h"
 #include "slod_select.hip.h"
 
@@ -22,7 +23,7 @@ namespace
     const SlodPatchDesc d = A.desc[blockIdx.x];
     constexpr int       W = 2 * S - 1, BW = 2 * W + 1, MP = 8 * T;
     constexpr int       BWP = BW + 1, BROWS = MP + 2 * W, bsz = (BROWS * BWP + 1) & ~1;
-    const int           tid = threadIdx.x, wave = tid >> 6;
+    const int           tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: roles, chain and LDS blocks are wave-uniform
     // (not const: the step loops of the forward sweep pass it through an empty asm each iteration, so
     // that per-lane addresses are recomputed there instead of being hoisted out of the loop and spilled)
     int                 lane = tid & 63;
@@ -842,13 +843,17 @@ namespace
       // block: the band product of the next line takes it from there (in place, as build_R does in the
       // forward sweep), so a line costs no workspace round trip beyond the prefetched V and Z.
       constexpr int TIB   = (MP + 15) / 16;
-      const bool    keepb = false && TIB <= 3 && nc <= 32 && !(SLOD_DG(A, 64));
+      const bool    keepb = TIB <= 3 && nc <= 32 && !(SLOD_DG(A, 64));
       if (keepb)
         for (int idx = t128; idx < m * nc; idx += 128)
           {
             const int i = idx / nc, c = idx - i * nc;
             Rb[i * ncs + c] = xg[(size_t)mid * xline + i * ncg + c];
           }
+      // (two instances of the loop, one per variant: sharing one loop made the register allocator spill
+      // the prefetched operands of the LDS-resident variant)
+      auto backward = [&](auto KEEP) __attribute__((always_inline)) {
+      constexpr bool keep_x = decltype(KEEP)::value;
       for (int t = tstart; t >= 0; --t)
         {
           while (nab > 0 && act[nab - 1] > t)
@@ -860,106 +865,124 @@ namespace
           __syncthreads(); // bands of this line are in LDS, X(prev) is in the workspace / the LDS block
           if (active && t > 0)
             fetch_B(line_of(chain, t - 1));
-          if (keepb)
+          if constexpr (keep_x)
             {
               const double *vl = vg + (size_t)line * vline;
               double       *xl = xg + (size_t)line * xline;
               const int     g = lane >> 3, cq = lane & 7; // rows T g .. T g + T - 1, columns cq + 8 (2 w2 + k)
               const int     colw = 16 * w2 + (lane & 15);  // GEMM: wave w2 owns column tile w2
-              double        av[MP / 4], zl[TIB][4], win[2][T + 2 * W];
+              const bool    gemm = active && 16 * w2 < nc;
+              constexpr int NPRE = 1; // row tiles of V requested before the band product
+              double        av[NPRE][MP / 4], zl[NPRE][4];
+              const double *zrow = zg + (size_t)line * xline;
+              const int     zc   = colw < nc ? inv[colw] : nc;
+              const bool    zok  = zc < nab; // the chain order is sorted by the first active step
+              auto          load_Z = [&](int ti, double (&dst)[4]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                  {
+                    const int    row = 16 * ti + (lane >> 4) + 4 * r;
+                    const bool   ok  = row < m && zok;
+                    const double z   = zrow[ok ? row * nab + zc : 0];
+                    dst[r]           = ok ? z : 0.0;
+                  }
+              };
+              if (gemm)
+                {
+#pragma unroll
+                  for (int ti = 0; ti < NPRE; ++ti)
+                    if (ti < tiles_i)
+                      {
+                        load_A(vl, ti, av[ti]);
+                        load_Z(ti, zl[ti]);
+                      }
+                }
+              double y[2][T];
               if (active)
                 {
-                  load_A(vl, 0, av);
-                  const double *zrow = zg + (size_t)line * xline;
-                  const int     zc   = colw < nc ? inv[colw] : nc;
-                  const bool    zok  = zc < nab; // the chain order is sorted by the first active step
-#pragma unroll
-                  for (int ti = 0; ti < TIB; ++ti)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                      {
-                        const int    row = 16 * ti + (lane >> 4) + 4 * r;
-                        const bool   ok  = row < m && zok;
-                        const double z   = zrow[ok ? row * nab + zc : 0];
-                        zl[ti][r]        = ok ? z : 0.0;
-                      }
+                  // Y = B(line -> prev) X(prev), X(prev) from the block, one column at a time
 #pragma unroll
                   for (int k = 0; k < 2; ++k)
                     {
                       const int c = cq + 8 * (2 * w2 + k);
+                      double    win[T + 2 * W];
 #pragma unroll
                       for (int e = 0; e < T + 2 * W; ++e)
                         {
                           const int    pr  = T * g + e - W;
                           const bool   inb = c < nc && pr >= 0 && pr < m;
                           const double x   = Rb[(inb ? pr : 0) * ncs + (inb ? c : 0)];
-                          win[k][e]        = inb ? x : 0.0;
+                          win[e]           = inb ? x : 0.0;
                         }
-                    }
-                }
-              __syncthreads(); // every window is in registers: the block may be rewritten
-              if (active)
-                {
-                  // Y = B(line -> prev) X(prev)
 #pragma unroll
-                  for (int ta = 0; ta < T; ++ta)
-                    {
-                      const int i = T * g + ta;
-                      double    bnd[BW];
-#pragma unroll
-                      for (int o = 0; o < BW; ++o)
-                        bnd[o] = Bn[(i + W) * BWP + o];
-#pragma unroll
-                      for (int k = 0; k < 2; ++k)
+                      for (int ta = 0; ta < T; ++ta)
                         {
-                          const int c = cq + 8 * (2 * w2 + k);
-                          double    v = 0.0;
+                          double v = 0.0;
 #pragma unroll
                           for (int o = 0; o < BW; ++o)
-                            v = fma(bnd[o], win[k][ta + o], v);
-                          if (c < nc && i < m)
-                            Rb[i * ncs + c] = v;
+                            v = fma(Bn[(T * g + ta + W) * BWP + o], win[ta + o], v);
+                          y[k][ta] = v;
                         }
                     }
                 }
-              __syncthreads();
-              double bq[MP / 4];
+              __syncthreads(); // every window is read: the block may be rewritten
               if (active)
+                {
+#pragma unroll
+                  for (int k = 0; k < 2; ++k)
+                    {
+                      const int c = cq + 8 * (2 * w2 + k);
+#pragma unroll
+                      for (int ta = 0; ta < T; ++ta)
+                        if (c < nc && T * g + ta < m)
+                          Rb[(T * g + ta) * ncs + c] = y[k][ta];
+                    }
+                }
+              __syncthreads(); // Y is complete
+              double bq[MP / 4];
+              if (gemm)
                 {
 #pragma unroll
                   for (int kk = 0; kk < MP / 4; ++kk)
                     bq[kk] = Rb[brow(kk) * ncs + colw];
                 }
-              __syncthreads(); // B operands are in registers: X(line) may replace Y
-              if (active && 16 * w2 < nc)
+              __syncthreads(); // every B operand is in registers: X(line) may replace Y
+              if (gemm)
                 {
-                  double an[MP / 4];
 #pragma unroll
                   for (int ti = 0; ti < TIB; ++ti)
                     if (ti < tiles_i)
                       {
-                        if (ti + 1 < TIB && ti + 1 < tiles_i)
-                          load_A(vl, ti + 1, an);
                         double4_t acc = {0.0, 0.0, 0.0, 0.0};
+                        double    zt[4];
+                        if (ti < NPRE)
+                          {
 #pragma unroll
-                        for (int kk = 0; kk < MP / 4; ++kk)
-                          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bq[kk], acc, 0, 0, 0);
+                            for (int kk = 0; kk < MP / 4; ++kk)
+                              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[ti < NPRE ? ti : 0][kk], bq[kk], acc, 0, 0, 0);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                              zt[r] = zl[ti < NPRE ? ti : 0][r];
+                          }
+                        else
+                          {
+                            double al[MP / 4];
+                            load_A(vl, ti, al);
+                            load_Z(ti, zt);
+#pragma unroll
+                            for (int kk = 0; kk < MP / 4; ++kk)
+                              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(al[kk], bq[kk], acc, 0, 0, 0);
+                          }
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                           {
                             const int row = 16 * ti + (lane >> 4) + 4 * r;
                             if (row < m && colw < nc)
                               {
-                                const double x        = zl[ti][r] - acc[r];
-                                xl[row * ncg + colw]  = x;
-                                Rb[row * ncs + colw]  = x;
+                                const double x       = zt[r] - acc[r];
+                                xl[row * ncg + colw] = x;
+                                Rb[row * ncs + colw] = x;
                               }
-                          }
-                        if (ti + 1 < TIB)
-                          {
-#pragma unroll
-                            for (int kk = 0; kk < MP / 4; ++kk)
-                              av[kk] = an[kk];
                           }
                       }
                 }
@@ -1038,6 +1061,11 @@ namespace
             }
           // the next iteration's first barrier orders the X and band writes before their readers
         }
+      };
+      if (keepb)
+        backward(std::true_type{});
+      else
+        backward(std::false_type{});
     }
     // Fused selection stage: the same workgroup goes on with M, D, the boundary trace, the
     // least squares, phi and psi of its patch (X is fresh in this CU's L2 slice).  Patches of
