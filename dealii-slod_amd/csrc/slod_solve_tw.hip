@@ -329,7 +329,7 @@ namespace
               __builtin_amdgcn_sched_barrier(0);
             }
         };
-        bool bad = false;
+        unsigned long long bad = 0; // lanes that saw a non-positive pivot, accumulated on the scalar unit
         auto sweep = [&]() __attribute__((always_inline)) {
           for (int ka = 0; ka * T < m; ++ka)
             {
@@ -349,26 +349,28 @@ namespace
                   __builtin_amdgcn_wave_barrier();
                   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                   const double piv = rowb[k];
-                  bad |= !(piv > 0.0);
-                  const double p = fast_rcp(piv);
-                  double       ri[T], sj[T];
+                  bad |= __builtin_amdgcn_ballot_w64(!(piv > 0.0));
+                  const double p = fast_rcp(piv), pn = -p;
+                  // the row is scaled by -1/pivot: the rank-1 update is then a plain multiply-add (no
+                  // negated copy of the column per pivot)
+                  double ri[T], sn[T];
 #pragma unroll
                   for (int ta = 0; ta < T; ++ta)
                     ri[ta] = rowb[T * gy + ta];
 #pragma unroll
                   for (int tb = 0; tb < T; ++tb)
-                    sj[tb] = rowb[T * gx + tb] * p;
+                    sn[tb] = rowb[T * gx + tb] * pn;
                   __builtin_amdgcn_wave_barrier();
 #pragma unroll
                   for (int ta = 0; ta < T; ++ta)
 #pragma unroll
                     for (int tb = 0; tb < T; ++tb)
-                      a[ta][tb] = fma(-ri[ta], sj[tb], a[ta][tb]);
+                      a[ta][tb] = fma(ri[ta], sn[tb], a[ta][tb]);
                   if (gy == ka)
                     {
 #pragma unroll
                       for (int tb = 0; tb < T; ++tb)
-                        a[a0][tb] = sj[tb];
+                        a[a0][tb] = -sn[tb];
                     }
                   if (gx == ka)
                     {
@@ -376,7 +378,7 @@ namespace
                       for (int ta = 0; ta < T; ++ta)
                         a[ta][a0] = ri[ta] * p;
                       if (gy == ka)
-                        a[a0][a0] = -p;
+                        a[a0][a0] = pn;
                     }
                   __builtin_amdgcn_sched_barrier(0);
                 }
@@ -453,7 +455,7 @@ namespace
             sweep();
             store_tile(vg + (size_t)mid * vline, -1.0);
           }
-        if (bad && lane == 0 && !SLOD_DG(A, -1))
+        if (bad != 0 && lane == 0 && !SLOD_DG(A, -1))
           atomicOr(A.status, 1);
         __builtin_amdgcn_s_setprio(0);
         __syncthreads(); // M2: V_mid is in the workspace
