@@ -873,6 +873,8 @@ namespace
               double       *xl = xg + (size_t)line * xline;
               const int     g = lane >> 3, cq = lane & 7; // rows T g .. T g + T - 1, columns cq + 8 (2 w2 + k)
               const int     colw = 16 * w2 + (lane & 15);  // GEMM: wave w2 owns column tile w2
+              // (band product and GEMM of a wave touch the same 16 columns of the block, its own: the
+              // phases of a line are ordered by wave barriers; only the bands need the workgroup barrier)
               const bool    gemm = active && 16 * w2 < nc;
               constexpr int NPRE = 1; // row tiles of V requested before the band product
               double        av[NPRE][MP / 4], zl[NPRE][4];
@@ -927,7 +929,9 @@ namespace
                         }
                     }
                 }
-              __syncthreads(); // every window is read: the block may be rewritten
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // every window is read: the block may be rewritten
               if (active)
                 {
 #pragma unroll
@@ -940,7 +944,9 @@ namespace
                           Rb[(T * g + ta) * ncs + c] = y[k][ta];
                     }
                 }
-              __syncthreads(); // Y is complete
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // Y is complete
               double bq[MP / 4];
               if (gemm)
                 {
@@ -948,7 +954,9 @@ namespace
                   for (int kk = 0; kk < MP / 4; ++kk)
                     bq[kk] = Rb[brow(kk) * ncs + colw];
                 }
-              __syncthreads(); // every B operand is in registers: X(line) may replace Y
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+              __builtin_amdgcn_wave_barrier();
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // every B operand is in registers: X(line) may replace Y
               if (gemm)
                 {
 #pragma unroll
