@@ -777,10 +777,10 @@ namespace
         if (nmy == nstp && nmy > 0)
           fwd_step(nstp - 1);
         __syncthreads(); // M1 (also: both chains' last Z are in the workspace)
-        __syncthreads(); // M2: V_mid is in the workspace
         if (chain == 0)
           {
-            // R_mid = F_mid - B^T Z(mid-1) - B'^T Z(mid+1); the bands are the last B of each chain
+            // R_mid = F_mid - B^T Z(mid-1) - B'^T Z(mid+1); the bands are the last B of each chain.
+            // Built while chain 0's Gauss-Jordan wave inverts the meeting line (it needs Z, not V_mid).
             const double *B0 = Bbuf(Bc0, n0 - 1);
             double       *ob = ocb + MP * ncs + MP + 3 * bsz; // other chain's Bc0
             const double *B1 = Bbuf(ob, n1 - 1);
@@ -797,6 +797,10 @@ namespace
               build_R(mid, B1, zg + (size_t)(mid + 1) * xline, na1, false, true, nc, nullptr, oinv, oact, n1 - 1, false);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+          }
+        __syncthreads(); // M2: V_mid is in the workspace
+        if (chain == 0)
+          {
             gemm_Z(mid, nc, xg + (size_t)mid * xline, ncg); // X_mid
           }
         __syncthreads(); // M3
