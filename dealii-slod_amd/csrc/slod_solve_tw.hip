@@ -82,6 +82,38 @@ namespace
     auto brow = [&](int kk) { return T * ((lane >> 4) + 4 * (kk / T)) + kk % T; };
 
     const int mid = L / 2;
+    // Row tile ti of X_mid = V_mid R_mid (R_mid in chain 0's LDS block), all columns: after the meeting
+    // line is inverted every wave of the workgroup takes one row tile (one operand round trip instead
+    // of one per tile in series on a single wave)
+    auto mid_tile = [&](int ti) __attribute__((always_inline)) {
+      const double *vl = vg + (size_t)mid * vline;
+      double       *xl = xg + (size_t)mid * xline;
+      const int     tiles_j = (nc + 15) >> 4;
+      double        av[MP / 4];
+      load_A(vl, ti, av);
+      for (int tj = 0; tj < tiles_j; tj += 2)
+        {
+          double4_t     acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+          const double *bp  = smem + 16 * tj + (lane & 15);
+          const bool    two = tj + 1 < tiles_j;
+#pragma unroll
+          for (int kk = 0; kk < MP / 4; ++kk)
+            {
+              acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bp[brow(kk) * ncs], acc0, 0, 0, 0);
+              if (two)
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bp[brow(kk) * ncs + 16], acc1, 0, 0, 0);
+            }
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            {
+              const int row = 16 * ti + (lane >> 4) + 4 * r, col = 16 * tj + (lane & 15);
+              if (row < m && col < nc)
+                xl[row * ncg + col] = acc0[r];
+              if (two && row < m && col + 16 < nc)
+                xl[row * ncg + col + 16] = acc1[r];
+            }
+        }
+    };
     const int n0 = mid, n1 = L - 1 - mid, nstp = n0 > n1 ? n0 : n1;
     const int nmy = chain == 0 ? n0 : n1; // lines of this chain
     const int dl  = chain == 0 ? 1 : -1;
@@ -459,6 +491,9 @@ namespace
           atomicOr(A.status, 1);
         __builtin_amdgcn_s_setprio(0);
         __syncthreads(); // M2: V_mid is in the workspace
+        if (!(SLOD_DG(A, 8)))
+          for (int ti = wave; 16 * ti < m; ti += 4)
+            mid_tile(ti);
         __syncthreads(); // M3: X_mid is in the workspace
       }
     else
@@ -799,10 +834,9 @@ namespace
             __builtin_amdgcn_wave_barrier();
           }
         __syncthreads(); // M2: V_mid is in the workspace
-        if (chain == 0)
-          {
-            gemm_Z(mid, nc, xg + (size_t)mid * xline, ncg); // X_mid
-          }
+        if (!(SLOD_DG(A, 8)))
+          for (int ti = wave; 16 * ti < m; ti += 4)
+            mid_tile(ti);
         __syncthreads(); // M3
       }
 
