@@ -361,6 +361,7 @@ namespace
               __builtin_amdgcn_sched_barrier(0);
             }
         };
+        double             acc_p[2] = {0.0, 0.0}; // diag: shader cycles of a pivot up to the scaled row / of its update
         unsigned long long bad = 0; // lanes that saw a non-positive pivot, accumulated on the scalar unit
         auto sweep = [&]() __attribute__((always_inline)) {
           for (int ka = 0; ka * T < m; ++ka)
@@ -371,6 +372,7 @@ namespace
                   const int k = T * ka + a0;
                   if (k >= m || ((SLOD_DG(A, 4)) && k > 0)) // wave-uniform
                     continue;
+                  const long long q0 = (SLOD_DG(A, (1 << 20))) ? clock64() : 0;
                   if (gy == ka)
                     {
 #pragma unroll
@@ -393,6 +395,14 @@ namespace
                   for (int tb = 0; tb < T; ++tb)
                     sn[tb] = rowb[T * gx + tb] * pn;
                   __builtin_amdgcn_wave_barrier();
+                  long long q1 = 0;
+                  if (SLOD_DG(A, (1 << 20)))
+                    {
+                      // (diag: the clock is read once the scaled row is in registers)
+                      double probe = sn[0] + ri[0];
+                      asm volatile("" : "+v"(probe));
+                      q1 = clock64();
+                    }
 #pragma unroll
                   for (int ta = 0; ta < T; ++ta)
 #pragma unroll
@@ -411,6 +421,14 @@ namespace
                         a[ta][a0] = ri[ta] * p;
                       if (gy == ka)
                         a[a0][a0] = pn;
+                    }
+                  if (SLOD_DG(A, (1 << 20)))
+                    {
+                      double probe = a[0][0] + a[T - 1][T - 1];
+                      asm volatile("" : "+v"(probe));
+                      const long long q2 = clock64();
+                      acc_p[0] += (double)(q1 - q0);
+                      acc_p[1] += (double)(q2 - q1);
                     }
                   __builtin_amdgcn_sched_barrier(0);
                 }
@@ -469,8 +487,13 @@ namespace
               }
           }
         if ((SLOD_DG(A, (1 << 20))) && tid == 0 && A.nc_max * A.nc_max >= 48)
-          for (int k = 0; k < 4; ++k)
-            A.ms[(size_t)blockIdx.x * A.nc_max * A.nc_max + 40 + k] = acc_t[k];
+          {
+            for (int k = 0; k < 4; ++k)
+              A.ms[(size_t)blockIdx.x * A.nc_max * A.nc_max + 40 + k] = acc_t[k];
+            if (A.nc_max * A.nc_max >= 52)
+              for (int k = 0; k < 2; ++k)
+                A.ms[(size_t)blockIdx.x * A.nc_max * A.nc_max + 48 + k] = acc_p[k];
+          }
         tstamp(2);
         // the meeting line: a0 = T_mid - W_0, a1 = -W_1
         if (chain == 1)

@@ -50,3 +50,7 @@ for kk, lst in per_cu.items():
         gj_per_simd[sd[0]] += 1; gj_per_simd[sd[1]] += 1
     load[tuple(sorted(gj_per_simd))] += 1
 print("CUs: %d; GJ waves per SIMD (sorted) histogram:" % len(per_cu), load.most_common(8))
+piv = buf.reshape(len(ids), ncm * ncm)[full][:, 48:50]
+npiv = 19 * 39  # 5x5-cell patch, n_sub 8: 39 interior lines of 39 dofs, 19 forward steps per chain (the meeting line is not counted)
+print("GJ wave, shader cycles per pivot (sums over the forward sweep / %d pivots): write -> barrier -> read -> reciprocal -> scaled row %.0f, rank-1 update and replacements %.0f" % (
+    npiv, piv[:, 0].mean() / npiv, piv[:, 1].mean() / npiv))
