@@ -367,7 +367,7 @@ def main():
             # same 78.6 TFLOP/s): "mfma" names that peak; what actually limits the kernel today is
             # the instruction issue / dependent-chain latency of its Gauss-Jordan waves
             "roofline": {"bound": "mfma",
-                         "limiter": "dependent chains per patch: Gauss-Jordan pivots in the forward sweep, exposed workspace-load latencies in the backward sweep (DESIGN section 6)",
+                         "limiter": "forward sweep: vector issue (two Gauss-Jordan waves + two helpers per SIMD, 57 VALU per pivot) and the CU's LDS unit on the pivot-row broadcast; backward sweep: workspace loads of V/Z per line (DESIGN section 6, measured on the device)",
                          "kernel": "k_solve_%s" % os.environ.get("SLOD_SOLVE", "tw") + (" (stencil assembly and selection stage fused in)" if ks[2] < 0.05 * ks[1] and ks[0] < 0.05 * ks[1] else (" (selection stage fused in)" if ks[2] < 0.05 * ks[1] else "")),
                          "achieved": achieved_tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / PEAK_FP64_TFLOPS, "traffic": traffic,
